@@ -1,0 +1,223 @@
+/*
+ * mpn.h — C ABI of libmpn_hip.so: the MI355X (gfx950) kernels behind the MultiPoseNet hot path.
+ *
+ * Boundary rules: extern "C", plain pointers + sizes, no torch types.  Every entry
+ * point enqueues work on the caller's stream (`hipStream_t` passed as void*), never allocates,
+ * never synchronises (except where stated), and returns 0 on success or the hipError_t code /
+ * a negative MPN_E* code on a bad argument.  All tensors are device pointers unless stated.
+ *
+ * Tensor model: activations are NHWC ("pixel-major"): element (b, h, w, c) of a tensor lives at
+ *     base + b*sB + (h*W + w)*sP + c            (strides in ELEMENTS, channel stride 1)
+ * Internal tensors keep their channel count padded to a multiple of 32 (pad lanes hold zeros) so
+ * every 64-byte K-chunk load is in bounds and 16-byte aligned.  dtype codes: 0 = f32, 1 = bf16.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference).
+ */
+#ifndef MPN_H_
+#define MPN_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPN_F32 0
+#define MPN_BF16 1
+
+#define MPN_E_BADARG (-2)
+#define MPN_E_UNSUPPORTED (-3)
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution (implicit GEMM on MFMA).  Replaces every nn.Conv2d / nn.Linear call site of
+ * network/fpn.py:14-26,42-76, network/posenet.py:36-46,78-89,133-135,165-186 (forward) and the
+ * autograd backward torch derives for them (training/trainer.py:251).
+ * -------------------------------------------------------------------------------------------*/
+typedef struct MpnConvParams {
+    const void* x;        /* gathered operand: fwd = input activations, dgrad = dY                */
+    const void* w;        /* fwd: [Cout][R][S][Cin]; dgrad: [Cout'][R][S][Cin'] = Wt (see below)    */
+    void* y;              /* output tensor                                                        */
+    const float* bias;    /* optional [Cout] f32                                                  */
+    const float* scale;   /* optional [Cout] f32 per-channel multiplier applied before bias       */
+    const void* res;      /* optional residual (same element type as y)                           */
+    float* stats;         /* optional [tilesP][Cout][2] per-tile (sum, sumsq) partials (BN train) */
+    int64_t x_sB, x_sH, x_sW;
+    int64_t y_sB, y_sP;
+    int64_t res_sB, res_sP;
+    int32_t B, H, W, Cin; /* source dims; Cin = contraction channels per tap (mult. of 64 bytes)  */
+    int32_t Ho, Wo, Cout, Cout_store; /* output dims; channels [Cout, Cout_store) are written 0   */
+    int32_t R, S, stride, pad;
+    int32_t mode;         /* 0: hi = ho*stride - pad + r ; 1 (dgrad): hi = (ho + pad - r)/stride   */
+    int32_t act;          /* 0 none, 1 relu, 2 sigmoid                                            */
+    int32_t res_mode;     /* 0 none, 1 same size, 2 nearest-upsampled from [res_H, res_W]          */
+    int32_t res_H, res_W;
+    int32_t accumulate;   /* y = y + result (act must be 0)                                       */
+    int32_t dtype;        /* element type of x, w                                                 */
+    int32_t out_f32;      /* 1: y (and res) are f32 even when dtype is bf16                       */
+} MpnConvParams;
+
+/* number of pixel tiles (rows of `stats`) mpn_conv_forward will use for this problem */
+int mpn_conv_stats_tiles(const MpnConvParams* p);
+int mpn_conv_forward(const MpnConvParams* p, void* stream);
+
+typedef struct MpnWgradParams {
+    const void* x;        /* forward input activations (gathered)                                 */
+    const void* dy;       /* output gradient, dense pixel-major: dy[p*dy_sP + cout]               */
+    float* dw;            /* [Cout][R][S][Cin] f32, ACCUMULATED into (dw += result)               */
+    float* ws;            /* workspace, >= chunks * Cout*R*S*Cin floats when chunks > 1           */
+    int64_t x_sB, x_sH, x_sW;
+    int64_t dy_sP;
+    int32_t B, H, W, Cin;
+    int32_t Ho, Wo, Cout;
+    int32_t R, S, stride, pad;
+    int32_t dtype;
+    int32_t chunks;       /* split of the B*Ho*Wo contraction; use mpn_conv_wgrad_chunks()        */
+} MpnWgradParams;
+
+int mpn_conv_wgrad_chunks(const MpnWgradParams* p);
+int mpn_conv_wgrad(const MpnWgradParams* p, void* stream);
+
+/* dst[i] (+)= sum_{c<chunks} ws[c*n + i]  — deterministic second stage of split reductions */
+int mpn_reduce_partials(const float* ws, int chunks, int64_t n, float* dst, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Parameter preparation (once per step): master f32 [Cout][R][S][Cin] -> compute-dtype copies.
+ * -------------------------------------------------------------------------------------------*/
+int mpn_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* Wt[ci][r][s][co_pad] = W[co][r][s][ci] (co >= Cout -> 0); ci_pad rows beyond Cin are zero too */
+int mpn_weight_transpose(const float* w, void* wt, int Cout, int RS, int Cin, int Cout_pad,
+                         int dtype, void* stream);
+/* copy f32 [Cout][K] -> dtype [Cout][Kpad] zero padded (used for narrow-Cin / linear layers) */
+int mpn_weight_pad_k(const float* w, void* dst, int Cout, int K, int Kpad, int dtype, void* stream);
+/* stem 7x7x3: W[64][7][7][3] f32 <-> packed [64][7][32] (slot s*4+c, c<3, s<7; rest zero) */
+int mpn_stem_pack_weight(const float* w, void* packed, int Cout, int dtype, void* stream);
+int mpn_stem_unpack_wgrad(const float* dpacked, float* dw, int Cout, void* stream);
+/* image NCHW f32 [B,3,H,W] -> zero-bordered NHWC4 [B][H+6][W+8][4] (pad 3 top/left) */
+int mpn_stem_pack_image(const float* img, int64_t sB, int64_t sC, int64_t sH, int64_t sW, void* dst,
+                        int B, int H, int W, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm2d (network/fpn.py:15-26,43) in train / eval mode, fused with ReLU and residual add
+ * (Bottleneck.forward, fpn.py:28-34).
+ * -------------------------------------------------------------------------------------------*/
+/* train: reduce conv-epilogue partials -> mean/invstd, scale/shift, update running stats */
+int mpn_bn_finalize_train(const float* stats, int tiles, int C, int64_t count, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var, float momentum,
+                          float eps, float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* eval / frozen: scale/shift from running statistics */
+int mpn_bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, float* mean, float* invstd,
+                         float* scale, float* shift, void* stream);
+/* z = act(y*scale + shift [+ res]);  all [P][Cs] dense pixel-major with pixel stride Cs */
+int mpn_bn_act_forward(const void* y, const void* res, void* z, const float* scale, const float* shift,
+                       int64_t P, int C, int Cs, int relu, int dtype, void* stream);
+/* backward, stage 1: g = dz * (z > 0 if relu); partial sums of g and g*xhat per channel */
+int mpn_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
+                      float* partial, int chunks, int64_t P, int C, int Cs, int relu, int dtype, void* stream);
+/* backward, stage 2: reduce partials; dgamma += , dbeta += (if non-null); coef[c] = {a, b} */
+int mpn_bn_bwd_finalize(const float* partial, int chunks, int C, int64_t count, float* dgamma, float* dbeta,
+                        float* coef, void* stream);
+/* backward, stage 3: dy = gamma*invstd*(g - a - xhat*b) (train) or g*scale (frozen: coef==NULL);
+ * dres (optional) receives / accumulates g */
+int mpn_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
+                     const float* gamma, const float* coef, void* dy, void* dres, int dres_accumulate,
+                     int64_t P, int C, int Cs, int relu, int dtype, void* stream);
+int mpn_bn_bwd_chunks(int64_t P, int C);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pooling / resampling / layout (fpn.py:84-100, posenet.py:180-184,296-315)
+ * -------------------------------------------------------------------------------------------*/
+int mpn_maxpool3x3s2_forward(const void* x, void* y, uint8_t* idx, int B, int H, int W, int Cs,
+                             int Ho, int Wo, int dtype, void* stream);
+int mpn_maxpool3x3s2_backward(const void* dy, const uint8_t* idx, void* dx, int B, int H, int W, int Cs,
+                              int Ho, int Wo, int dtype, void* stream);
+/* dcoarse[b,h,w,:] (+)= sum over the fine pixels whose nearest source is (h,w) of dfine */
+int mpn_upsample_nearest_backward(const void* dfine, void* dcoarse, int B, int Hf, int Wf, int Hc, int Wc,
+                                  int Cs, int accumulate, int dtype, void* stream);
+/* out[b, oh, ow, c_off + c] = src[b, oh*Hs/Ho, ow*Ws/Wo, c]  (nearest; writes a channel slice) */
+int mpn_upsample_nearest_slice(const void* src, void* dst, int B, int Hs, int Ws, int Cs_src,
+                               int Ho, int Wo, int Cs_dst, int c_off, int dtype, void* stream);
+/* dsrc[b,h,w,c] = sum over fine pixels of ddst[b,oh,ow,c_off+c] */
+int mpn_upsample_nearest_slice_backward(const void* ddst, void* dsrc, int B, int Hs, int Ws, int Cs_src,
+                                        int Ho, int Wo, int Cs_dst, int c_off, int dtype, void* stream);
+/* API edge: padded internal f32/bf16 [B,h,w,Cs] -> exact f32 [B,H,W,C] (nearest up by H/h) and back */
+int mpn_export_f32(const void* src, int src_dtype, float* dst, int B, int Hs, int Ws, int Cs, int C,
+                   int Ho, int Wo, int64_t dst_sB, int64_t dst_sP, void* stream);
+int mpn_import_grad(const float* ddst, int64_t ddst_sB, int64_t ddst_sP, void* dsrc, int dst_dtype,
+                    int B, int Hs, int Ws, int Cs, int C, int Ho, int Wo, void* stream);
+/* generic strided f32 NCHW -> dense NHWC f32 [B,H,W,C] (ground-truth maps) */
+int mpn_nchw_to_nhwc_f32(const float* src, int64_t sB, int64_t sC, int64_t sH, int64_t sW, float* dst,
+                         int B, int C, int H, int W, void* stream);
+/* detection-head edge: padded internal [B,HW,Cs] <-> dense f32 [B, HW*C] slice of the [B,A,C/9] output
+ * (the permute+view+cat of network/posenet.py:67-69,111-117,327-328 without any copy kernels in between) */
+int mpn_det_pack(const void* src, int src_dtype, float* dst, int B, int64_t HW, int Cs, int C, int64_t dst_sB, void* stream);
+int mpn_det_unpack(const float* ddst, void* dsrc, int dst_dtype, int B, int64_t HW, int Cs, int C, int64_t dst_sB, void* stream);
+int mpn_relu_backward(const void* dz, const void* z, void* dx, int64_t n, int accumulate, int dtype, void* stream);
+int mpn_add_inplace(void* dst, const void* src, int64_t n, int dtype, void* stream);
+int mpn_channel_sum(const void* dy, int dy_dtype, int64_t P, int C, int Cs, float* partial, int chunks, void* stream);
+int mpn_channel_sum_chunks(int64_t P, int C);
+
+/* ---------------------------------------------------------------------------------------------
+ * Losses (posenet.py:367-445, losses.py:5-137)
+ * -------------------------------------------------------------------------------------------*/
+/* preds: 5 device pointers (f32 NHWC [B,h,w,*] with pixel stride pred_sP[j]); gt/wgt dense NHWC f32
+ * [B,h,w,18].  out[0..4] = per-level means, out[5] = total, out[6] = max_ht, out[7] = min_ht. */
+int mpn_mse_heatmap_forward(const float* const* preds, const int64_t* pred_sP, const float* gt, const float* wgt,
+                            int64_t npix, float* partial, int chunks, float* out, void* stream);
+/* dpred_j[p, c] = gscale * 2*w^2*(pred - gt)/N for c < 18, 0 for c in [18, Cj) */
+int mpn_mse_heatmap_backward(const float* const* preds, float* const* dpreds, const int64_t* pred_sP,
+                             const int64_t* dpred_sP, const int32_t* pred_C, const float* gt, const float* wgt,
+                             int64_t npix, const float* gscale, void* stream);
+int mpn_mse_chunks(int64_t npix);
+/* focal + smooth-L1.  cls [B,A] f32 (post-sigmoid), reg [B,A,4], anchors [A,4], anno [B,maxN,5].
+ * out[0] = cls loss, out[1] = reg loss (batch means).  per_img [B][4] scratch. */
+int mpn_focal_blocks(int A);   /* partial needs B * mpn_focal_blocks(A) * 4 floats */
+int mpn_focal_forward(const float* cls, const float* reg, const float* anchors, const float* anno,
+                      int B, int A, int maxN, float* partial, float* per_img, float* out, void* stream);
+int mpn_focal_backward(const float* cls, const float* reg, const float* anchors, const float* anno,
+                       int B, int A, int maxN, const float* per_img, const float* gscale,
+                       float* dcls, float* dreg, void* stream);
+/* dlogit = dp * p * (1-p) */
+int mpn_sigmoid_backward(const float* dp, const float* p, float* dlogit, int64_t n, void* stream);
+/* PRN: out = softmax(a + res) rowwise (posenet.py:345-347); BCE mean (posenet.py:436-439) */
+int mpn_add_softmax_rows(const float* a, const float* res, float* out, int rows, int cols, void* stream);
+int mpn_bce_chunks(int64_t n);
+int mpn_bce_mean_forward(const float* p, const float* label, int64_t n, float* partial, int chunks, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Boxes (network/utils.py:19-61, network/posenet.py:266-271)
+ * -------------------------------------------------------------------------------------------*/
+int mpn_box_decode_clip(const float* anchors, const float* deltas, float* boxes, int B, int A,
+                        float img_w, float img_h, void* stream);
+/* compact image-0 candidates with score > thresh into dets[n,5] (x1,y1,x2,y2,score) + src index;
+ * order preserved (ascending anchor index).  count[0] receives n. */
+int mpn_score_filter(const float* boxes, const float* scores, int A, float thresh, float* dets,
+                     int32_t* src_idx, int32_t* count, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * NMS — replaces lib/nms: gpu_nms (src/nms_cuda.c:17-67), _nms/nms_kernel
+ * (src/cuda/nms_kernel.cu:26-83) and the sort/gather of pth_nms (pth_nms.py:25-44).
+ * dets [n,5] f32 device, unsorted.  mode 0: suppress if IoU > thresh (reference GPU path),
+ * mode 1: IoU >= thresh (reference CPU path, nms.c:59).  keep_out [n] i64 device receives ORIGINAL
+ * indices in descending-score order (ties: lower index first); num_out [1] i64 device.
+ * workspace: mpn_nms_workspace_bytes(n) bytes of device memory.
+ * -------------------------------------------------------------------------------------------*/
+int64_t mpn_nms_workspace_bytes(int64_t n);
+int mpn_nms(const float* dets, int64_t n, float thresh, int mode, int64_t* keep_out, int64_t* num_out,
+            void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer: torch.optim.Adam semantics (training/multipose_keypoint_train.py:106-110), fused over
+ * a flat f32 arena.  step_size/bias corrections are computed on the host and passed in.
+ * -------------------------------------------------------------------------------------------*/
+int mpn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay,
+                  float bias_correction1, float bias_correction2_sqrt, float grad_scale, void* stream);
+int mpn_fill_f32(float* dst, float v, int64_t n, void* stream);
+
+/* library self-description */
+const char* mpn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPN_H_ */

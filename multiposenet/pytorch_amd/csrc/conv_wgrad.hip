@@ -1,0 +1,349 @@
+// conv_wgrad.hip — weight-gradient convolution on MFMA for gfx950.
+//
+// Replaces the weight half of autograd's conv backward (training/trainer.py:251) for every
+// nn.Conv2d / nn.Linear of network/fpn.py and network/posenet.py.
+//
+//   dW[cout][r][s][cin] += sum_{pixels p} dY[p][cout] * X[gather(p, r, s)][cin]
+//
+// GEMM view per tap (r,s):  D[cin][cout] = sum_p X^T[cin][p] * dY[p][cout]  (contraction = pixels)
+//   * MFMA "A" rows = cin, "B" cols = cout  -> each lane owns 4 consecutive cin of one cout, i.e.
+//     a float4 of the [Cout][R][S][Cin] gradient (the master-weight memory layout).
+//   * both operands arrive pixel-major (channels contiguous), i.e. K-strided.  f32 path: the
+//     16x16x4 f32 MFMA takes ONE k per lane, so tiles stay [k][channel] in LDS and fragments are
+//     conflict-free ds_read_b32.  bf16 path: 16x16x32 wants 8 consecutive k per lane; two pixel rows
+//     are interleaved in registers into (k, k+1) dwords and written channel-major ([channel][k],
+//     80-byte rows) so fragments are one ds_read_b128 exactly like the forward kernel.
+//   * the pixel contraction is split into `chunks` slices across workgroups; slices write f32
+//     partials to a workspace and mpn_reduce_partials adds them into dW in a fixed order
+//     (deterministic; no atomics).  chunks == 1 accumulates straight into dW.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+struct PixState {      // incremental (b, ho, wo) walker over the dense output-pixel index
+    int b, ho, wo;
+    __device__ __forceinline__ void init(long pix, int Ho, int Wo) {
+        const long hw = (long)Ho * Wo;
+        b = (int)(pix / hw);
+        const long rem = pix - (long)b * hw;
+        ho = (int)(rem / Wo);
+        wo = (int)(rem - (long)ho * Wo);
+    }
+    __device__ __forceinline__ void advance(int n, int Ho, int Wo) {
+        wo += n;
+        while (wo >= Wo) { wo -= Wo; if (++ho == Ho) { ho = 0; ++b; } }
+    }
+    __device__ __forceinline__ PixState next(int Ho, int Wo) const {
+        PixState q = *this;
+        if (++q.wo == Wo) { q.wo = 0; if (++q.ho == Ho) { q.ho = 0; ++q.b; } }
+        return q;
+    }
+};
+
+template <typename T, int TM, int TN>
+struct WgCfg {
+    static constexpr bool kBf16 = sizeof(T) == 2;
+    static constexpr int KP = kBf16 ? 32 : 16;            // pixels per k-step
+    static constexpr int WTM = TM / 2, WTN = TN / 2;      // 2 x 2 waves
+    static constexpr int MM = (WTM + 15) / 16, MN = (WTN + 15) / 16;
+    static constexpr int RS_A = kBf16 ? 80 : (TM + 16) * 4;   // LDS row stride (bytes)
+    static constexpr int RS_B = kBf16 ? 80 : (TN + 16) * 4;
+    static constexpr int A_BYTES = kBf16 ? TM * 80 : 16 * RS_A;
+    static constexpr int B_BYTES = kBf16 ? TN * 80 : 16 * RS_B;
+    static constexpr int BUF_BYTES = A_BYTES + B_BYTES;
+    // load units per operand: bf16 -> (16 k-pairs) x (TM/8 groups); f32 -> (16 k) x (TM/4 vecs)
+    static constexpr int UA = kBf16 ? 16 * (TM / 8) : 16 * (TM / 4);
+    static constexpr int UB = kBf16 ? 16 * (TN / 8) : 16 * (TN / 4);
+    static constexpr int A_PER_T = (UA + 255) / 256;
+    static constexpr int B_PER_T = (UB + 255) / 256;
+};
+
+template <typename T, int TM, int TN>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(const MpnWgradParams p, long chunk_pixels) {
+    using C = WgCfg<T, TM, TN>;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * C::BUF_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tilesM = (p.Cin + TM - 1) / TM, tilesN = (p.Cout + TN - 1) / TN;
+    const int taps = p.R * p.S;
+    int bid = blockIdx.x;
+    const int tn = bid % tilesN; bid /= tilesN;
+    const int tm = bid % tilesM; bid /= tilesM;
+    const int tap = bid % taps; bid /= taps;
+    const int chunk = bid;
+    const int r = tap / p.S, s = tap - r * p.S;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const long P = (long)p.B * p.Ho * p.Wo;
+    const long k_begin = (long)chunk * chunk_pixels;
+    long k_end = k_begin + chunk_pixels; if (k_end > P) k_end = P;
+    const T* __restrict__ X = (const T*)p.x;
+    const T* __restrict__ DY = (const T*)p.dy;
+    const int dy_cs = ((p.Cout + 31) / 32) * 32;    // dY channel storage (pad lanes are zero)
+    constexpr int V = 16 / (int)sizeof(T);
+
+    // ---------------- per-thread load descriptors ----------------
+    // A (X, gathered): unit -> (k index within step, channel offset)
+    int a_k[C::A_PER_T], a_c[C::A_PER_T]; bool a_on[C::A_PER_T]; PixState a_px[C::A_PER_T];
+    int b_k[C::B_PER_T], b_c[C::B_PER_T]; bool b_on[C::B_PER_T];
+#pragma unroll
+    for (int q = 0; q < C::A_PER_T; ++q) {
+        const int u = tid + 256 * q;
+        if (C::kBf16) { a_k[q] = (u & 15) * 2; a_c[q] = (u >> 4) * 8; }
+        else          { a_k[q] = u / (TM / 4); a_c[q] = (u % (TM / 4)) * 4; }
+        a_on[q] = (u < C::UA) && (m0 + a_c[q] < p.Cin);
+        long pix = k_begin + a_k[q]; if (pix >= P) pix = P - 1;
+        a_px[q].init(pix, p.Ho, p.Wo);
+    }
+#pragma unroll
+    for (int q = 0; q < C::B_PER_T; ++q) {
+        const int u = tid + 256 * q;
+        if (C::kBf16) { b_k[q] = (u & 15) * 2; b_c[q] = (u >> 4) * 8; }
+        else          { b_k[q] = u / (TN / 4); b_c[q] = (u % (TN / 4)) * 4; }
+        b_on[q] = (u < C::UB) && (n0 + b_c[q] < dy_cs);
+    }
+
+    f32x4_t acc[C::MM][C::MN];
+#pragma unroll
+    for (int i = 0; i < C::MM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::MN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NR = C::kBf16 ? 2 : 1;      // pixel rows per unit
+    u32x4_t ra[C::A_PER_T][NR], rb[C::B_PER_T][NR];
+    const u32x4_t zero4 = (u32x4_t){0u, 0u, 0u, 0u};
+    long k0 = k_begin;
+
+    auto xload = [&](const PixState& ps, long pix, int c) -> u32x4_t {
+        const int hi = ps.ho * p.stride - p.pad + r, wi = ps.wo * p.stride - p.pad + s;
+        const bool ok = (pix < k_end) && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        const long off = (long)ps.b * p.x_sB + (long)hi * p.x_sH + (long)wi * p.x_sW + m0 + c;
+        return ok ? *reinterpret_cast<const u32x4_t*>(X + off) : zero4;
+    };
+    auto gload = [&]() {
+#pragma unroll
+        for (int q = 0; q < C::A_PER_T; ++q) {
+            if (a_on[q]) {
+                const long pix = k0 + a_k[q];
+                ra[q][0] = xload(a_px[q], pix, a_c[q]);
+                if (NR == 2) ra[q][NR - 1] = xload(a_px[q].next(p.Ho, p.Wo), pix + 1, a_c[q]);
+                a_px[q].advance(C::KP, p.Ho, p.Wo);
+            } else {
+#pragma unroll
+                for (int e = 0; e < NR; ++e) ra[q][e] = zero4;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < C::B_PER_T; ++q) {
+#pragma unroll
+            for (int e = 0; e < NR; ++e) {
+                const long pix = k0 + b_k[q] + e;
+                const bool ok = b_on[q] && pix < k_end;
+                rb[q][e] = ok ? *reinterpret_cast<const u32x4_t*>(DY + pix * p.dy_sP + n0 + b_c[q]) : zero4;
+            }
+        }
+        k0 += C::KP;
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* la = lds + buf * C::BUF_BYTES;
+        unsigned char* lb = la + C::A_BYTES;
+        if (C::kBf16) {
+#pragma unroll
+            for (int q = 0; q < C::A_PER_T; ++q) {
+                if (tid + 256 * q < C::UA) {
+                    const u32x4_t e = ra[q][0], o = ra[q][NR - 1];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const unsigned ew = e[i >> 1], ow = o[i >> 1];
+                        const unsigned v = (i & 1) ? ((ew >> 16) | (ow & 0xffff0000u)) : ((ew & 0xffffu) | (ow << 16));
+                        *reinterpret_cast<unsigned*>(la + (a_c[q] + i) * 80 + a_k[q] * 2) = v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < C::B_PER_T; ++q) {
+                if (tid + 256 * q < C::UB) {
+                    const u32x4_t e = rb[q][0], o = rb[q][NR - 1];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const unsigned ew = e[i >> 1], ow = o[i >> 1];
+                        const unsigned v = (i & 1) ? ((ew >> 16) | (ow & 0xffff0000u)) : ((ew & 0xffffu) | (ow << 16));
+                        *reinterpret_cast<unsigned*>(lb + (b_c[q] + i) * 80 + b_k[q] * 2) = v;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < C::A_PER_T; ++q)
+                if (tid + 256 * q < C::UA)
+                    *reinterpret_cast<u32x4_t*>(la + a_k[q] * C::RS_A + a_c[q] * 4) = ra[q][0];
+#pragma unroll
+            for (int q = 0; q < C::B_PER_T; ++q)
+                if (tid + 256 * q < C::UB)
+                    *reinterpret_cast<u32x4_t*>(lb + b_k[q] * C::RS_B + b_c[q] * 4) = rb[q][0];
+        }
+    };
+
+    const long span = k_end - k_begin;
+    const int nsteps = span > 0 ? (int)((span + C::KP - 1) / C::KP) : 0;
+    if (nsteps > 0) {
+        gload();
+        lstore(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nsteps; ++it) {
+        const bool more = (it + 1) < nsteps;
+        if (more) gload();
+        const unsigned char* la = lds + (it & 1) * C::BUF_BYTES;
+        const unsigned char* lb = la + C::A_BYTES;
+        if (C::kBf16) {
+            u32x4_t fa[C::MM], fb[C::MN];
+#pragma unroll
+            for (int i = 0; i < C::MM; ++i)
+                fa[i] = *reinterpret_cast<const u32x4_t*>(la + (wm * C::WTM + i * 16 + (lane & 15)) * 80 + (lane >> 4) * 16);
+#pragma unroll
+            for (int j = 0; j < C::MN; ++j)
+                fb[j] = *reinterpret_cast<const u32x4_t*>(lb + (wn * C::WTN + j * 16 + (lane & 15)) * 80 + (lane >> 4) * 16);
+#pragma unroll
+            for (int i = 0; i < C::MM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::MN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[i]),
+                                                                        __builtin_bit_cast(bf16x8_t, fb[j]), acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                float fa[C::MM], fb[C::MN];
+                const int krow = kq * 4 + (lane >> 4);
+#pragma unroll
+                for (int i = 0; i < C::MM; ++i)
+                    fa[i] = *reinterpret_cast<const float*>(la + krow * C::RS_A + (wm * C::WTM + i * 16 + (lane & 15)) * 4);
+#pragma unroll
+                for (int j = 0; j < C::MN; ++j)
+                    fb[j] = *reinterpret_cast<const float*>(lb + krow * C::RS_B + (wn * C::WTN + j * 16 + (lane & 15)) * 4);
+#pragma unroll
+                for (int i = 0; i < C::MM; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::MN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (more) lstore((it + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    const long NW = (long)p.Cout * taps * p.Cin;
+    float* __restrict__ dst = (p.chunks > 1) ? (p.ws + (long)chunk * NW) : p.dw;
+    const bool add = (p.chunks == 1);
+#pragma unroll
+    for (int i = 0; i < C::MM; ++i) {
+        const int ml = wm * C::WTM + i * 16 + (lane >> 4) * 4;
+        const int cin = m0 + ml;
+        if (cin >= p.Cin) continue;
+#pragma unroll
+        for (int j = 0; j < C::MN; ++j) {
+            const int nl = wn * C::WTN + j * 16 + (lane & 15);
+            const int cout = n0 + nl;
+            if (cout >= p.Cout) continue;
+            float* q = dst + ((long)cout * taps + tap) * p.Cin + cin;
+            float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            if (add) {
+                const float4 o = *reinterpret_cast<const float4*>(q);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *reinterpret_cast<float4*>(q) = v;
+        }
+    }
+}
+
+__global__ void reduce_partials_kernel(const float* __restrict__ ws, int chunks, long n, float* __restrict__ dst, int accumulate) {
+    const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    if (i4 + 3 < n) {
+        float4 a = accumulate ? *reinterpret_cast<const float4*>(dst + i4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < chunks; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(ws + (long)c * n + i4);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        *reinterpret_cast<float4*>(dst + i4) = a;
+    } else {
+        for (long i = i4; i < n; ++i) {
+            float a = accumulate ? dst[i] : 0.f;
+            for (int c = 0; c < chunks; ++c) a += ws[(long)c * n + i];
+            dst[i] = a;
+        }
+    }
+}
+
+inline int pick_tile(int n) { return n > 64 ? 128 : (n > 32 ? 64 : 32); }
+
+template <typename T, int TM>
+int launch_wgrad_n(const MpnWgradParams& p, int tn, long grid, long chunk_pixels, hipStream_t st) {
+    if (tn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<T, TM, 128>), dim3((unsigned)grid), dim3(256), 0, st, p, chunk_pixels);
+    else if (tn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, TM, 64>), dim3((unsigned)grid), dim3(256), 0, st, p, chunk_pixels);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<T, TM, 32>), dim3((unsigned)grid), dim3(256), 0, st, p, chunk_pixels);
+    return mpn_launch_status();
+}
+
+template <typename T>
+int launch_wgrad(const MpnWgradParams& p, hipStream_t st) {
+    const int tm = pick_tile(p.Cin), tn = pick_tile(p.Cout);
+    const long tilesM = (p.Cin + tm - 1) / tm, tilesN = (p.Cout + tn - 1) / tn;
+    const long P = (long)p.B * p.Ho * p.Wo;
+    const int kp = sizeof(T) == 2 ? 32 : 16;
+    long chunk_pixels = (P + p.chunks - 1) / p.chunks;
+    chunk_pixels = ((chunk_pixels + kp - 1) / kp) * kp;
+    const long grid = tilesM * tilesN * p.R * p.S * p.chunks;
+    if (grid <= 0 || grid > 0x7fffffffL) return MPN_E_BADARG;
+    int rc;
+    if (tm == 128) rc = launch_wgrad_n<T, 128>(p, tn, grid, chunk_pixels, st);
+    else if (tm == 64) rc = launch_wgrad_n<T, 64>(p, tn, grid, chunk_pixels, st);
+    else rc = launch_wgrad_n<T, 32>(p, tn, grid, chunk_pixels, st);
+    if (rc != 0) return rc;
+    if (p.chunks > 1) {
+        const long n = (long)p.Cout * p.R * p.S * p.Cin;
+        const long threads = (n + 3) / 4;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+                           (const float*)p.ws, p.chunks, n, p.dw, 1);
+        rc = mpn_launch_status();
+    }
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int mpn_conv_wgrad_chunks(const MpnWgradParams* p) {
+    if (!p) return MPN_E_BADARG;
+    const int tm = pick_tile(p->Cin), tn = pick_tile(p->Cout);
+    const long tiles = (long)((p->Cin + tm - 1) / tm) * ((p->Cout + tn - 1) / tn) * p->R * p->S;
+    const long P = (long)p->B * p->Ho * p->Wo;
+    long want = (1536 + tiles - 1) / tiles;           // ~6 workgroups per CU in flight
+    const long maxc = (P + 511) / 512;                 // keep >= 512 pixels per slice
+    if (want > maxc) want = maxc;
+    if (want < 1) want = 1;
+    if (want > 256) want = 256;
+    return (int)want;
+}
+
+extern "C" int mpn_conv_wgrad(const MpnWgradParams* pp, void* stream) {
+    if (!pp) return MPN_E_BADARG;
+    const MpnWgradParams& p = *pp;
+    MPN_CHECK_ARG(p.x && p.dy && p.dw);
+    MPN_CHECK_ARG(p.dtype == MPN_F32 || p.dtype == MPN_BF16);
+    MPN_CHECK_ARG(p.B > 0 && p.Ho > 0 && p.Wo > 0 && p.Cin > 0 && p.Cout > 0);
+    MPN_CHECK_ARG(p.Cin % 8 == 0);
+    MPN_CHECK_ARG(p.chunks >= 1 && (p.chunks == 1 || p.ws));
+    hipStream_t st = (hipStream_t)stream;
+    if (p.dtype == MPN_F32) return launch_wgrad<float>(p, st);
+    return launch_wgrad<bf16_t>(p, st);
+}
+
+extern "C" int mpn_reduce_partials(const float* ws, int chunks, int64_t n, float* dst, int accumulate, void* stream) {
+    MPN_CHECK_ARG(ws && dst && chunks >= 1 && n > 0);
+    const long threads = (n + 3) / 4;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       ws, chunks, (long)n, dst, accumulate);
+    return mpn_launch_status();
+}

@@ -1,0 +1,390 @@
+// losses.hip — heat-map MSE, focal + smooth-L1 detection loss, PRN softmax / BCE for gfx950.
+//
+// Reference: build_keypoint_loss network/posenet.py:367-403 (5 x MSELoss(size_average=True) over
+// pred[:, :18]*w vs w*gt, plus max/min of the final heat-map), FocalLoss network/losses.py:27-137
+// (alpha .25, gamma 2, IoU<.4 negative / >=.5 positive, smooth-L1 beta 1/9, per-image python loop
+// replaced by one thread per (image, anchor)), calc_iou losses.py:5-22, PRN softmax + BCELoss
+// posenet.py:345-347,427-445.  All reductions are two-stage and deterministic (no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int MSE_CHUNK = 256 * 16;     // elements (pixel*18 + c) per block
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+struct PredPtrs { const float* p[5]; long sP[5]; };
+struct DPredPtrs { float* p[5]; long sP[5]; int C[5]; };
+
+// partial[block][8] = {sum_j (5), unused, max, min}
+__global__ void mse_fwd_kernel(PredPtrs pr, const float* __restrict__ gt, const float* __restrict__ wgt, long nelem,
+                               float* __restrict__ partial) {
+    __shared__ float sh[4][8];
+    float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float mx = -INFINITY, mn = INFINITY;
+    const long base = (long)blockIdx.x * MSE_CHUNK;
+    for (int it = 0; it < 16; ++it) {
+        const long e = base + it * 256 + threadIdx.x;
+        if (e < nelem) {
+            const long pix = e / 18; const int c = (int)(e - pix * 18);
+            const float w = wgt[e], g = gt[e];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const float pv = pr.p[j][pix * pr.sP[j] + c];
+                const float d = pv * w - w * g;
+                s[j] += d * d;
+                if (j == 4) { mx = fmaxf(mx, pv); mn = fminf(mn, pv); }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) s[j] = wave_sum(s[j]);
+    mx = wave_max(mx); mn = wave_min(mn);
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) sh[wave][j] = s[j];
+        sh[wave][6] = mx; sh[wave][7] = mn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* o = partial + (long)blockIdx.x * 8;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) o[j] = sh[0][j] + sh[1][j] + sh[2][j] + sh[3][j];
+        o[5] = 0.f;
+        o[6] = fmaxf(fmaxf(sh[0][6], sh[1][6]), fmaxf(sh[2][6], sh[3][6]));
+        o[7] = fminf(fminf(sh[0][7], sh[1][7]), fminf(sh[2][7], sh[3][7]));
+    }
+}
+
+__global__ void mse_finalize_kernel(const float* __restrict__ partial, int chunks, double nelem, float* __restrict__ out) {
+    __shared__ double sh[256][5];
+    __shared__ float shm[256][2];
+    double s[5] = {0, 0, 0, 0, 0};
+    float mx = -INFINITY, mn = INFINITY;
+    for (int i = threadIdx.x; i < chunks; i += 256) {
+        const float* o = partial + (long)i * 8;
+        for (int j = 0; j < 5; ++j) s[j] += (double)o[j];
+        mx = fmaxf(mx, o[6]); mn = fminf(mn, o[7]);
+    }
+    for (int j = 0; j < 5; ++j) sh[threadIdx.x][j] = s[j];
+    shm[threadIdx.x][0] = mx; shm[threadIdx.x][1] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot[5] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < 256; ++i) {
+            for (int j = 0; j < 5; ++j) tot[j] += sh[i][j];
+            mx = fmaxf(mx, shm[i][0]); mn = fminf(mn, shm[i][1]);
+        }
+        float total = 0.f;
+        for (int j = 0; j < 5; ++j) { const float l = (float)(tot[j] / nelem); out[j] = l; total += l; }
+        out[5] = total; out[6] = mx; out[7] = mn;
+    }
+}
+
+// one thread per (pixel, channel < Cmax); dpred_j[pix*sP + c] = gs*2*w*(p*w - w*g)/N, 0 for c >= 18
+__global__ void mse_bwd_kernel(PredPtrs pr, DPredPtrs dp, const float* __restrict__ gt, const float* __restrict__ wgt,
+                               long npix, int Cmax, const float* __restrict__ gscale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * Cmax) return;
+    const long pix = i / Cmax; const int c = (int)(i - pix * Cmax);
+    const float gs = gscale ? gscale[0] : 1.f;
+    const float k = gs * 2.0f / (float)((double)npix * 18.0);
+    float w = 0.f, g = 0.f;
+    if (c < 18) { w = wgt[pix * 18 + c]; g = gt[pix * 18 + c]; }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        if (c >= dp.C[j] || dp.p[j] == nullptr) continue;
+        float v = 0.f;
+        if (c < 18) {
+            const float pv = pr.p[j][pix * pr.sP[j] + c];
+            v = k * w * (pv * w - w * g);
+        }
+        dp.p[j][pix * dp.sP[j] + c] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------- focal loss
+struct Assign { float iou_max; int arg; };
+
+__device__ __forceinline__ Assign assign_anchor(const float4 a, const float* __restrict__ anno, int maxN) {
+    // losses.py:5-22 (no +1; union clamped at 1e-8), argmax = first maximum (losses.py:59)
+    Assign r; r.iou_max = -1.f; r.arg = -1;
+    const float area_a = (a.z - a.x) * (a.w - a.y);
+    for (int n = 0; n < maxN; ++n) {
+        const float* g = anno + n * 5;
+        if (g[4] == -1.f) continue;
+        const float area_b = (g[2] - g[0]) * (g[3] - g[1]);
+        float iw = fminf(a.z, g[2]) - fmaxf(a.x, g[0]);
+        float ih = fminf(a.w, g[3]) - fmaxf(a.y, g[1]);
+        iw = fmaxf(iw, 0.f); ih = fmaxf(ih, 0.f);
+        float ua = area_a + area_b - iw * ih;
+        ua = fmaxf(ua, 1e-8f);
+        const float iou = (iw * ih) / ua;
+        if (iou > r.iou_max) { r.iou_max = iou; r.arg = n; }
+    }
+    return r;
+}
+
+__device__ __forceinline__ void reg_targets(const float4 a, const float* g, float t[4]) {
+    // losses.py:97-121
+    const float aw = a.z - a.x, ah = a.w - a.y;
+    const float acx = a.x + 0.5f * aw, acy = a.y + 0.5f * ah;
+    float gw = g[2] - g[0], gh = g[3] - g[1];
+    const float gcx = g[0] + 0.5f * gw, gcy = g[1] + 0.5f * gh;
+    gw = fmaxf(gw, 1.f); gh = fmaxf(gh, 1.f);
+    t[0] = ((gcx - acx) / aw) / 0.1f;
+    t[1] = ((gcy - acy) / ah) / 0.1f;
+    t[2] = logf(gw / aw) / 0.2f;
+    t[3] = logf(gh / ah) / 0.2f;
+}
+
+// grid (blocksA, B); partial[(b*blocksA + blk)*4] = {cls_sum, reg_sum, npos, nvalid_anno}
+__global__ void focal_fwd_kernel(const float* __restrict__ cls, const float* __restrict__ reg, const float* __restrict__ anchors,
+                                 const float* __restrict__ anno, int A, int maxN, float* __restrict__ partial) {
+    __shared__ float sh[4][3];
+    const int b = blockIdx.y;
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const float* an = anno + (long)b * maxN * 5;
+    float cl = 0.f, rl = 0.f, np = 0.f;
+    int nvalid = 0;
+    for (int n = 0; n < maxN; ++n) nvalid += (an[n * 5 + 4] != -1.f);
+    if (a < A && nvalid > 0) {
+        const float4 box = *reinterpret_cast<const float4*>(anchors + (long)a * 4);
+        const Assign as = assign_anchor(box, an, maxN);
+        float p = cls[(long)b * A + a];
+        p = fminf(fmaxf(p, 1e-4f), 1.0f - 1e-4f);
+        if (as.iou_max >= 0.5f) {
+            const float om = 1.f - p;
+            cl = 0.25f * om * om * (-logf(p));
+            np = 1.f;
+            float t[4]; reg_targets(box, an + as.arg * 5, t);
+            const float4 r = *reinterpret_cast<const float4*>(reg + ((long)b * A + a) * 4);
+            const float rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = fabsf(t[k] - rr[k]);
+                rl += (d <= 1.0f / 9.0f) ? 0.5f * 9.0f * d * d : d - 0.5f / 9.0f;
+            }
+        } else if (as.iou_max < 0.4f) {
+            cl = 0.75f * p * p * (-logf(1.f - p));
+        }
+    }
+    cl = wave_sum(cl); rl = wave_sum(rl); np = wave_sum(np);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sh[wave][0] = cl; sh[wave][1] = rl; sh[wave][2] = np; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* o = partial + ((long)b * gridDim.x + blockIdx.x) * 4;
+        o[0] = sh[0][0] + sh[1][0] + sh[2][0] + sh[3][0];
+        o[1] = sh[0][1] + sh[1][1] + sh[2][1] + sh[3][1];
+        o[2] = sh[0][2] + sh[1][2] + sh[2][2] + sh[3][2];
+        o[3] = (float)nvalid;
+    }
+}
+
+// one block; per_img[b] = {cls_sum, reg_sum, npos, nvalid}; out = {cls_loss, reg_loss}
+__global__ void focal_finalize_kernel(const float* __restrict__ partial, int B, int blocksA, float* __restrict__ per_img,
+                                      float* __restrict__ out) {
+    __shared__ double shc[256], shr[256];
+    double csum = 0.0, rsum = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        double c = 0.0, r = 0.0, n = 0.0; float nv = 0.f;
+        for (int k = 0; k < blocksA; ++k) {
+            const float* o = partial + ((long)b * blocksA + k) * 4;
+            c += o[0]; r += o[1]; n += o[2]; nv = o[3];
+        }
+        per_img[b * 4 + 0] = (float)c; per_img[b * 4 + 1] = (float)r; per_img[b * 4 + 2] = (float)n; per_img[b * 4 + 3] = nv;
+        if (nv > 0.f) {
+            csum += (double)((float)c / fmaxf((float)n, 1.f));
+            if (n > 0.0) rsum += (double)((float)r / (4.f * (float)n));
+        }
+    }
+    shc[threadIdx.x] = csum; shr[threadIdx.x] = rsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double c = 0.0, r = 0.0;
+        for (int i = 0; i < 256; ++i) { c += shc[i]; r += shr[i]; }
+        out[0] = (float)(c / B); out[1] = (float)(r / B);
+    }
+}
+
+__global__ void focal_bwd_kernel(const float* __restrict__ cls, const float* __restrict__ reg, const float* __restrict__ anchors,
+                                 const float* __restrict__ anno, int B, int A, int maxN, const float* __restrict__ per_img,
+                                 const float* __restrict__ gscale, float* __restrict__ dcls, float* __restrict__ dreg) {
+    const int b = blockIdx.y;
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= A) return;
+    const float gs = gscale ? gscale[0] : 1.f;
+    const float* an = anno + (long)b * maxN * 5;
+    const float npos = per_img[b * 4 + 2], nvalid = per_img[b * 4 + 3];
+    float dc = 0.f;
+    float dr[4] = {0.f, 0.f, 0.f, 0.f};
+    if (nvalid > 0.f) {
+        const float4 box = *reinterpret_cast<const float4*>(anchors + (long)a * 4);
+        const Assign as = assign_anchor(box, an, maxN);
+        const float praw = cls[(long)b * A + a];
+        const bool inrange = (praw >= 1e-4f) && (praw <= 1.0f - 1e-4f);     // clamp passes gradient inside [min, max]
+        const float p = fminf(fmaxf(praw, 1e-4f), 1.0f - 1e-4f);
+        const float kc = gs / ((float)B * fmaxf(npos, 1.f));
+        if (as.iou_max >= 0.5f) {
+            const float om = 1.f - p;
+            if (inrange) dc = kc * 0.25f * (2.f * om * logf(p) - om * om / p);
+            float t[4]; reg_targets(box, an + as.arg * 5, t);
+            const float4 r = *reinterpret_cast<const float4*>(reg + ((long)b * A + a) * 4);
+            const float rr[4] = {r.x, r.y, r.z, r.w};
+            const float kr = gs / ((float)B * 4.f * npos);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float e = rr[k] - t[k];
+                const float d = fabsf(e);
+                dr[k] = kr * ((d <= 1.0f / 9.0f) ? 9.0f * e : (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)));
+            }
+        } else if (as.iou_max < 0.4f) {
+            if (inrange) dc = kc * 0.75f * (-2.f * p * logf(1.f - p) + p * p / (1.f - p));
+        }
+    }
+    dcls[(long)b * A + a] = dc;
+    *reinterpret_cast<float4*>(dreg + ((long)b * A + a) * 4) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+}
+
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ p, float* __restrict__ dl, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float pv = p[i]; dl[i] = dp[i] * pv * (1.f - pv); }
+}
+
+// ------------------------------------------------------------------------------- PRN pieces
+__global__ void add_softmax_rows_kernel(const float* __restrict__ a, const float* __restrict__ res, float* __restrict__ out, int cols) {
+    __shared__ float sh[4];
+    __shared__ float bc;
+    const long row = blockIdx.x;
+    const float* pa = a + row * cols; const float* pr = res + row * cols; float* po = out + row * cols;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < cols; i += 256) mx = fmaxf(mx, pa[i] + pr[i]);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) bc = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    __syncthreads();
+    mx = bc;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < cols; i += 256) s += expf(pa[i] + pr[i] - mx);
+    s = wave_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bc = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    const float inv = 1.0f / bc;
+    for (int i = threadIdx.x; i < cols; i += 256) po[i] = expf(pa[i] + pr[i] - mx) * inv;
+}
+
+__global__ void bce_partial_kernel(const float* __restrict__ p, const float* __restrict__ y, long n, float* __restrict__ partial) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    const long base = (long)blockIdx.x * 4096;
+    for (int it = 0; it < 16; ++it) {
+        const long i = base + it * 256 + threadIdx.x;
+        if (i < n) {
+            const float lp = fmaxf(logf(p[i]), -100.f), lq = fmaxf(logf(1.f - p[i]), -100.f);
+            s += -(y[i] * lp + (1.f - y[i]) * lq);
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ void mean_finalize_kernel(const float* __restrict__ partial, int chunks, double n, float* __restrict__ out) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < chunks; i += 256) s += (double)partial[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int i = 0; i < 256; ++i) t += sh[i]; out[0] = (float)(t / n); }
+}
+
+}  // namespace
+
+extern "C" int mpn_mse_chunks(int64_t npix) { return (int)((npix * 18 + MSE_CHUNK - 1) / MSE_CHUNK); }
+
+extern "C" int mpn_mse_heatmap_forward(const float* const* preds, const int64_t* pred_sP, const float* gt, const float* wgt,
+                                       int64_t npix, float* partial, int chunks, float* out, void* stream) {
+    MPN_CHECK_ARG(preds && pred_sP && gt && wgt && partial && out && npix > 0);
+    MPN_CHECK_ARG(chunks == mpn_mse_chunks(npix));
+    PredPtrs pr;
+    for (int j = 0; j < 5; ++j) { pr.p[j] = preds[j]; pr.sP[j] = (long)pred_sP[j]; MPN_CHECK_ARG(preds[j] != nullptr); }
+    hipLaunchKernelGGL(mse_fwd_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, pr, gt, wgt, (long)npix * 18, partial);
+    hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, chunks, (double)npix * 18.0, out);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_mse_heatmap_backward(const float* const* preds, float* const* dpreds, const int64_t* pred_sP,
+                                        const int64_t* dpred_sP, const int32_t* pred_C, const float* gt, const float* wgt,
+                                        int64_t npix, const float* gscale, void* stream) {
+    MPN_CHECK_ARG(preds && dpreds && pred_sP && dpred_sP && pred_C && gt && wgt && npix > 0);
+    PredPtrs pr; DPredPtrs dp; int cmax = 0;
+    for (int j = 0; j < 5; ++j) {
+        pr.p[j] = preds[j]; pr.sP[j] = (long)pred_sP[j];
+        dp.p[j] = dpreds[j]; dp.sP[j] = (long)dpred_sP[j]; dp.C[j] = pred_C[j];
+        if (pred_C[j] > cmax) cmax = pred_C[j];
+    }
+    const long n = (long)npix * cmax;
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pr, dp, gt, wgt, (long)npix, cmax, gscale);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_focal_blocks(int A) { return (A + 255) / 256; }
+
+extern "C" int mpn_focal_forward(const float* cls, const float* reg, const float* anchors, const float* anno, int B, int A,
+                                 int maxN, float* partial, float* per_img, float* out, void* stream) {
+    MPN_CHECK_ARG(cls && reg && anchors && anno && partial && per_img && out && B > 0 && A > 0 && maxN > 0);
+    const int blocksA = (A + 255) / 256;
+    hipLaunchKernelGGL(focal_fwd_kernel, dim3(blocksA, B), dim3(256), 0, (hipStream_t)stream, cls, reg, anchors, anno, A, maxN, partial);
+    hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, B, blocksA, per_img, out);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_focal_backward(const float* cls, const float* reg, const float* anchors, const float* anno, int B, int A,
+                                  int maxN, const float* per_img, const float* gscale, float* dcls, float* dreg, void* stream) {
+    MPN_CHECK_ARG(cls && reg && anchors && anno && per_img && dcls && dreg && B > 0 && A > 0 && maxN > 0);
+    hipLaunchKernelGGL(focal_bwd_kernel, dim3((A + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, cls, reg, anchors, anno, B, A, maxN,
+                       per_img, gscale, dcls, dreg);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_sigmoid_backward(const float* dp, const float* p, float* dlogit, int64_t n, void* stream) {
+    MPN_CHECK_ARG(dp && p && dlogit && n > 0);
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dp, p, dlogit, (long)n);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_add_softmax_rows(const float* a, const float* res, float* out, int rows, int cols, void* stream) {
+    MPN_CHECK_ARG(a && res && out && rows > 0 && cols > 0);
+    hipLaunchKernelGGL(add_softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, a, res, out, cols);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_bce_chunks(int64_t n) { return (int)((n + 4095) / 4096); }
+
+extern "C" int mpn_bce_mean_forward(const float* p, const float* label, int64_t n, float* partial, int chunks, float* out, void* stream) {
+    MPN_CHECK_ARG(p && label && partial && out && n > 0 && chunks == mpn_bce_chunks(n));
+    hipLaunchKernelGGL(bce_partial_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, p, label, (long)n, partial);
+    hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, chunks, (double)n, out);
+    return mpn_launch_status();
+}

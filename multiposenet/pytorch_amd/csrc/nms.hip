@@ -1,0 +1,225 @@
+// nms.hip — box decode/clip, score filter and wavefront-level greedy NMS for gfx950.
+//
+// Replaces lib/nms (the reference's only native code):
+//   pth_nms            lib/nms/pth_nms.py:5-45        (areas, descending sort, order[keep])
+//   gpu_nms            lib/nms/src/nms_cuda.c:17-67   (mask alloc, D2H of the mask, serial host scan)
+//   nms_kernel/devIoU  lib/nms/src/cuda/nms_kernel.cu:16-70
+//   cpu_nms            lib/nms/src/nms.c:4-69         (mode 1: '>=' comparison)
+// and BBoxTransform / ClipBoxes (network/utils.py:19-61) + the score>0.05 gather
+// (network/posenet.py:269-279).
+//
+// Design (CDNA4: one wave == 64 lanes == one u64 mask word):
+//   1. rank sort: rank[i] = #{j : s_j > s_i or (s_j == s_i and j < i)} — O(N^2) compares, unique
+//      ranks, deterministic tie rule (lower index first); boxes are scattered to sorted order.
+//   2. mask: one wave per 64x64 tile of the UPPER triangle; lane t owns row box t, column boxes are
+//      broadcast lane-to-lane (v_readlane) — no LDS; the reference also fills the lower triangle,
+//      which its scan never reads.
+//   3. scan ON DEVICE (the reference copies the whole N*N/64 mask to the host): one workgroup walks
+//      the 64-box blocks; the diagonal word resolves intra-block suppression with scalar bit ops,
+//      kept rows are OR-ed into the removal vector in parallel.  Only `keep`/`num` leave the GPU.
+// IoU arithmetic is op-for-op devIoU (+1 pixel convention); this file is compiled with
+// -ffp-contract=off so mask bits equal the CPU oracle's bit for bit.
+#include "common.h"
+
+namespace {
+
+__global__ void box_decode_clip_kernel(const float* __restrict__ anchors, const float* __restrict__ deltas,
+                                       float* __restrict__ boxes, int B, int A, float img_w, float img_h) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * A) return;
+    const int a = (int)(i % A);
+    const float4 an = *reinterpret_cast<const float4*>(anchors + (long)a * 4);
+    const float4 d = *reinterpret_cast<const float4*>(deltas + i * 4);
+    // utils.py:21-41 (mean 0, std .1 .1 .2 .2)
+    const float w = an.z - an.x, h = an.w - an.y;
+    const float cx = an.x + 0.5f * w, cy = an.y + 0.5f * h;
+    const float dx = d.x * 0.1f, dy = d.y * 0.1f, dw = d.z * 0.2f, dh = d.w * 0.2f;
+    const float pcx = cx + dx * w, pcy = cy + dy * h;
+    const float pw = expf(dw) * w, ph = expf(dh) * h;
+    float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
+    // utils.py:55-59
+    x1 = fmaxf(x1, 0.f); y1 = fmaxf(y1, 0.f); x2 = fminf(x2, img_w); y2 = fminf(y2, img_h);
+    *reinterpret_cast<float4*>(boxes + i * 4) = make_float4(x1, y1, x2, y2);
+}
+
+// single workgroup (1024 threads), order-preserving compaction of image-0 candidates
+__global__ void score_filter_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, int A, float thresh,
+                                    float* __restrict__ dets, int* __restrict__ src_idx, int* __restrict__ count) {
+    __shared__ int wave_cnt[16];
+    __shared__ int base_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int a0 = 0; a0 < A; a0 += 1024) {
+        const int a = a0 + threadIdx.x;
+        const bool pass = (a < A) && (scores[a] > thresh);
+        const unsigned long long m = __ballot(pass);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (pass) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            const float4 b = *reinterpret_cast<const float4*>(boxes + (long)a * 4);
+            float* o = dets + (long)pos * 5;
+            o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w; o[4] = scores[a];
+            src_idx[pos] = a;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wave_cnt[w]; base_s += t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count[0] = base_s;
+}
+
+// ---------------------------------------------------------------------------------- NMS
+__global__ void nms_rank_kernel(const float* __restrict__ dets, int n, float* __restrict__ sorted, int* __restrict__ order) {
+    __shared__ float ssc[1024];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float si = (i < n) ? dets[(long)i * 5 + 4] : 0.f;
+    int rank = 0;
+    for (int j0 = 0; j0 < n; j0 += 1024) {
+        for (int t = threadIdx.x; t < 1024; t += blockDim.x) ssc[t] = (j0 + t < n) ? dets[(long)(j0 + t) * 5 + 4] : 0.f;
+        __syncthreads();
+        const int lim = (n - j0) < 1024 ? (n - j0) : 1024;
+        for (int t = 0; t < lim; ++t) {
+            const float sj = ssc[t];
+            rank += (sj > si) || (sj == si && (j0 + t) < i);
+        }
+        __syncthreads();
+    }
+    if (i < n) {
+        order[rank] = i;
+        const float* s = dets + (long)i * 5;
+        float* d = sorted + (long)rank * 5;
+        d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3]; d[4] = s[4];
+    }
+}
+
+__device__ __forceinline__ float dev_iou(const float a0, const float a1, const float a2, const float a3,
+                                         const float b0, const float b1, const float b2, const float b3) {
+    // nms_kernel.cu:16-24, op for op
+    const float left = fmaxf(a0, b0), right = fminf(a2, b2);
+    const float top = fmaxf(a1, b1), bottom = fminf(a3, b3);
+    const float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
+    const float interS = width * height;
+    const float Sa = (a2 - a0 + 1) * (a3 - a1 + 1);
+    const float Sb = (b2 - b0 + 1) * (b3 - b1 + 1);
+    return interS / (Sa + Sb - interS);
+}
+
+// grid (col_blocks, col_blocks), block 64 (one wave); only col >= row tiles do work
+__global__ void __launch_bounds__(64) nms_mask_kernel(const float* __restrict__ sorted, int n, float thresh, int mode,
+                                                      unsigned long long* __restrict__ mask, int cb) {
+    const int row_blk = blockIdx.y, col_blk = blockIdx.x;
+    if (col_blk < row_blk) return;
+    const int t = threadIdx.x;
+    const int row = row_blk * 64 + t, col = col_blk * 64 + t;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+    if (col < n) { const float* q = sorted + (long)col * 5; c0 = q[0]; c1 = q[1]; c2 = q[2]; c3 = q[3]; }
+    if (row < n) { const float* q = sorted + (long)row * 5; r0 = q[0]; r1 = q[1]; r2 = q[2]; r3 = q[3]; }
+    const int col_size = (n - col_blk * 64) < 64 ? (n - col_blk * 64) : 64;
+    unsigned long long bits = 0ull;
+    const int start = (row_blk == col_blk) ? t + 1 : 0;       // nms_kernel.cu:58-61
+    for (int i = 0; i < col_size; ++i) {
+        const float b0 = __shfl(c0, i, 64), b1 = __shfl(c1, i, 64), b2 = __shfl(c2, i, 64), b3 = __shfl(c3, i, 64);
+        const float iou = dev_iou(r0, r1, r2, r3, b0, b1, b2, b3);
+        const bool hit = (mode == 0) ? (iou > thresh) : (iou >= thresh);
+        if (hit && i >= start) bits |= 1ull << i;
+    }
+    if (row < n) mask[(long)row * cb + col_blk] = bits;
+}
+
+// one workgroup of 1024 threads
+__global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ order,
+                                                        int n, int cb, unsigned long long* __restrict__ remv,
+                                                        int64_t* __restrict__ keep_out, int64_t* __restrict__ num_out) {
+    __shared__ unsigned long long keep_word;
+    __shared__ int base_cnt;
+    const int tid = threadIdx.x;
+    for (int j = tid; j < cb; j += 1024) remv[j] = 0ull;
+    if (tid == 0) base_cnt = 0;
+    __syncthreads();
+    for (int bi = 0; bi < cb; ++bi) {
+        if (tid < 64) {
+            const int row = bi * 64 + tid;
+            const unsigned long long diag = (row < n) ? mask[(long)row * cb + bi] : 0ull;
+            unsigned long long cur = remv[bi];
+            unsigned long long kept = 0ull;
+            const int lim = (n - bi * 64) < 64 ? (n - bi * 64) : 64;
+            for (int t = 0; t < lim; ++t) {
+                const unsigned long long dt = __shfl(diag, t, 64);
+                if (!((cur >> t) & 1ull)) { kept |= 1ull << t; cur |= dt; }
+            }
+            if ((kept >> tid) & 1ull) {
+                const int pos = base_cnt + __popcll(kept & ((1ull << tid) - 1ull));
+                keep_out[pos] = (int64_t)order[row];
+            }
+            if (tid == 0) keep_word = kept;
+        }
+        __syncthreads();
+        const unsigned long long kept = keep_word;
+        if (kept) {
+            for (int j = bi + 1 + tid; j < cb; j += 1024) {
+                unsigned long long acc = remv[j];
+                unsigned long long k = kept;
+                while (k) {
+                    const int t = __ffsll((long long)k) - 1;
+                    k &= k - 1ull;
+                    acc |= mask[(long)(bi * 64 + t) * cb + j];
+                }
+                remv[j] = acc;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) base_cnt += __popcll(kept);
+        __syncthreads();
+    }
+    if (tid == 0) num_out[0] = (int64_t)base_cnt;
+}
+
+inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" int mpn_box_decode_clip(const float* anchors, const float* deltas, float* boxes, int B, int A, float img_w,
+                                   float img_h, void* stream) {
+    MPN_CHECK_ARG(anchors && deltas && boxes && B > 0 && A > 0);
+    const long n = (long)B * A;
+    hipLaunchKernelGGL(box_decode_clip_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, anchors, deltas,
+                       boxes, B, A, img_w, img_h);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_score_filter(const float* boxes, const float* scores, int A, float thresh, float* dets, int32_t* src_idx,
+                                int32_t* count, void* stream) {
+    MPN_CHECK_ARG(boxes && scores && dets && src_idx && count && A > 0);
+    hipLaunchKernelGGL(score_filter_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, boxes, scores, A, thresh, dets, src_idx, count);
+    return mpn_launch_status();
+}
+
+extern "C" int64_t mpn_nms_workspace_bytes(int64_t n) {
+    if (n <= 0) return 256;
+    const long cb = (n + 63) / 64;
+    return align_up(n * 5 * 4, 256) + align_up(n * 4, 256) + align_up(cb * 8, 256) + align_up(n * cb * 8, 256);
+}
+
+extern "C" int mpn_nms(const float* dets, int64_t n, float thresh, int mode, int64_t* keep_out, int64_t* num_out,
+                       void* workspace, void* stream) {
+    MPN_CHECK_ARG(num_out && (mode == 0 || mode == 1));
+    hipStream_t st = (hipStream_t)stream;
+    if (n <= 0) return (int)hipMemsetAsync(num_out, 0, sizeof(int64_t), st);
+    MPN_CHECK_ARG(dets && keep_out && workspace && n < (1 << 30));
+    const int N = (int)n;
+    const int cb = (N + 63) / 64;
+    char* ws = (char*)workspace;
+    float* sorted = (float*)ws;               ws += align_up((long)N * 5 * 4, 256);
+    int* order = (int*)ws;                    ws += align_up((long)N * 4, 256);
+    unsigned long long* remv = (unsigned long long*)ws; ws += align_up((long)cb * 8, 256);
+    unsigned long long* mask = (unsigned long long*)ws;
+    hipLaunchKernelGGL(nms_rank_kernel, dim3((N + 255) / 256), dim3(256), 0, st, dets, N, sorted, order);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb), dim3(64), 0, st, (const float*)sorted, N, thresh, mode, mask, cb);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), 0, st, (const unsigned long long*)mask, (const int*)order, N, cb, remv,
+                       keep_out, num_out);
+    return mpn_launch_status();
+}

@@ -1,0 +1,182 @@
+// weight_prep.hip — per-step parameter preparation + fused Adam for gfx950.
+//
+// Master parameters live in ONE flat f32 arena whose per-tensor physical layout is
+// [Cout][R][S][Cin] (a channels_last view of the reference's [Cout,Cin,R,S] state_dict entry, so
+// checkpoint keys/shapes are unchanged: network/net_utils.py:32-34).  Each step the compute-dtype
+// operand copies are refreshed from it:
+//   * forward operand  : same layout, cast to bf16 (one launch over the whole arena)
+//   * dgrad operand    : Wt[Cin][R][S][Cout_pad]  (LDS-tiled 32x32 transpose, one launch per conv)
+//   * stem (7x7x3)     : [64][7][32] packing that turns the Cin=3 stem into a Cin=32 "row" conv
+// Adam follows torch.optim.Adam (training/multipose_keypoint_train.py:106-110, trainer.py:259).
+#include "common.h"
+
+namespace {
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i >= n) return;
+    if (i + 7 < n) {
+        const float4 a = *reinterpret_cast<const float4*>(src + i);
+        const float4 b = *reinterpret_cast<const float4*>(src + i + 4);
+        uint4 o;
+        o.x = (uint32_t)f2bf(a.x) | ((uint32_t)f2bf(a.y) << 16);
+        o.y = (uint32_t)f2bf(a.z) | ((uint32_t)f2bf(a.w) << 16);
+        o.z = (uint32_t)f2bf(b.x) | ((uint32_t)f2bf(b.y) << 16);
+        o.w = (uint32_t)f2bf(b.z) | ((uint32_t)f2bf(b.w) << 16);
+        *reinterpret_cast<uint4*>(dst + i) = o;
+    } else {
+        for (long k = i; k < n; ++k) dst[k] = f2bf(src[k]);
+    }
+}
+
+// grid (ceil(Cin/32), ceil(Cout_pad/32), RS), block (32, 8)
+template <typename T>
+__global__ void weight_transpose_kernel(const float* __restrict__ w, T* __restrict__ wt, int Cout, int RS, int Cin, int Cout_pad) {
+    __shared__ float tile[32][33];
+    const int rs = blockIdx.z;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    for (int k = threadIdx.y; k < 32; k += 8) {
+        const int co = co0 + k, ci = ci0 + threadIdx.x;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) v = w[((long)co * RS + rs) * Cin + ci];
+        tile[k][threadIdx.x] = v;
+    }
+    __syncthreads();
+    for (int k = threadIdx.y; k < 32; k += 8) {
+        const int ci = ci0 + k, co = co0 + threadIdx.x;
+        if (ci < Cin && co < Cout_pad) Elem<T>::st(wt + ((long)ci * RS + rs) * Cout_pad + co, tile[threadIdx.x][k]);
+    }
+}
+
+template <typename T>
+__global__ void weight_pad_k_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout, int K, int Kpad) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)Cout * Kpad) return;
+    const int co = (int)(i / Kpad), k = (int)(i - (long)co * Kpad);
+    Elem<T>::st(dst + i, k < K ? w[(long)co * K + k] : 0.f);
+}
+
+// W[co][r][s][c] (7x7x3) -> packed[co][r][s*4 + c], slots with c==3 or s==7 are zero
+template <typename T>
+__global__ void stem_pack_weight_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * 7 * 32) return;
+    const int slot = i & 31, r = (i >> 5) % 7, co = i / (7 * 32);
+    const int s = slot >> 2, c = slot & 3;
+    float v = 0.f;
+    if (s < 7 && c < 3) v = w[((co * 7 + r) * 7 + s) * 3 + c];
+    Elem<T>::st(dst + i, v);
+}
+
+__global__ void stem_unpack_wgrad_kernel(const float* __restrict__ dp, float* __restrict__ dw, int Cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * 147) return;
+    const int c = i % 3, s = (i / 3) % 7, r = (i / 21) % 7, co = i / 147;
+    dw[i] += dp[(co * 7 + r) * 32 + s * 4 + c];
+}
+
+// NCHW f32 [B,3,H,W] (arbitrary strides) -> [B][H+6][W+8][4] zero bordered (3 top/left)
+template <typename T>
+__global__ void stem_pack_image_kernel(const float* __restrict__ img, long sB, long sC, long sH, long sW,
+                                       T* __restrict__ dst, int B, int H, int W) {
+    const int Hp = H + 6, Wp = W + 8;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one padded pixel per thread
+    if (i >= (long)B * Hp * Wp) return;
+    const int wp = (int)(i % Wp), hp = (int)((i / Wp) % Hp), b = (int)(i / ((long)Wp * Hp));
+    const int h = hp - 3, w = wp - 3;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (h >= 0 && h < H && w >= 0 && w < W) {
+        const float* q = img + b * sB + h * sH + w * sW;
+        v[0] = q[0]; v[1] = q[sC]; v[2] = q[2 * sC];
+    }
+    T* d = dst + i * 4;
+    Elem<T>::st(d + 0, v[0]); Elem<T>::st(d + 1, v[1]); Elem<T>::st(d + 2, v[2]); Elem<T>::st(d + 3, 0.f);
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const int cnt = (i + 3 < n) ? 4 : (int)(n - i);
+    for (int k = 0; k < cnt; ++k) {
+        float gr = g[i + k] * gscale;
+        const float pv = p[i + k];
+        if (wd != 0.f) gr += wd * pv;
+        const float mk = b1 * m[i + k] + (1.f - b1) * gr;
+        const float vk = b2 * v[i + k] + (1.f - b2) * gr * gr;
+        m[i + k] = mk; v[i + k] = vk;
+        const float denom = sqrtf(vk) / bc2_sqrt + eps;
+        p[i + k] = pv - (lr / bc1) * (mk / denom);
+    }
+}
+
+__global__ void fill_kernel(float* __restrict__ dst, float v, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+
+inline unsigned nblk(long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+extern "C" int mpn_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    MPN_CHECK_ARG(src && dst && n > 0);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(nblk(n, 2048)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, (long)n);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_weight_transpose(const float* w, void* wt, int Cout, int RS, int Cin, int Cout_pad, int dtype, void* stream) {
+    MPN_CHECK_ARG(w && wt && Cout > 0 && RS > 0 && Cin > 0 && Cout_pad >= Cout);
+    dim3 grid((Cin + 31) / 32, (Cout_pad + 31) / 32, RS), block(32, 8);
+    if (dtype == MPN_F32) hipLaunchKernelGGL(weight_transpose_kernel<float>, grid, block, 0, (hipStream_t)stream, w, (float*)wt, Cout, RS, Cin, Cout_pad);
+    else hipLaunchKernelGGL(weight_transpose_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, w, (bf16_t*)wt, Cout, RS, Cin, Cout_pad);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_weight_pad_k(const float* w, void* dst, int Cout, int K, int Kpad, int dtype, void* stream) {
+    MPN_CHECK_ARG(w && dst && Cout > 0 && K > 0 && Kpad >= K);
+    const long n = (long)Cout * Kpad;
+    if (dtype == MPN_F32) hipLaunchKernelGGL(weight_pad_k_kernel<float>, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (float*)dst, Cout, K, Kpad);
+    else hipLaunchKernelGGL(weight_pad_k_kernel<bf16_t>, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst, Cout, K, Kpad);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_stem_pack_weight(const float* w, void* packed, int Cout, int dtype, void* stream) {
+    MPN_CHECK_ARG(w && packed && Cout > 0);
+    const long n = (long)Cout * 7 * 32;
+    if (dtype == MPN_F32) hipLaunchKernelGGL(stem_pack_weight_kernel<float>, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (float*)packed, Cout);
+    else hipLaunchKernelGGL(stem_pack_weight_kernel<bf16_t>, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)packed, Cout);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_stem_unpack_wgrad(const float* dpacked, float* dw, int Cout, void* stream) {
+    MPN_CHECK_ARG(dpacked && dw && Cout > 0);
+    hipLaunchKernelGGL(stem_unpack_wgrad_kernel, dim3(nblk((long)Cout * 147, 256)), dim3(256), 0, (hipStream_t)stream, dpacked, dw, Cout);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_stem_pack_image(const float* img, int64_t sB, int64_t sC, int64_t sH, int64_t sW, void* dst,
+                                   int B, int H, int W, int dtype, void* stream) {
+    MPN_CHECK_ARG(img && dst && B > 0 && H > 0 && W > 0);
+    const long n = (long)B * (H + 6) * (W + 8);
+    if (dtype == MPN_F32) hipLaunchKernelGGL(stem_pack_image_kernel<float>, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, img, (long)sB, (long)sC, (long)sH, (long)sW, (float*)dst, B, H, W);
+    else hipLaunchKernelGGL(stem_pack_image_kernel<bf16_t>, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, img, (long)sB, (long)sC, (long)sH, (long)sW, (bf16_t*)dst, B, H, W);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
+                             float bias_correction2_sqrt, float grad_scale, void* stream) {
+    MPN_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0);
+    hipLaunchKernelGGL(adam_kernel, dim3(nblk(n, 1024)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
+                       (long)n, lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2_sqrt, grad_scale);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_fill_f32(float* dst, float v, int64_t n, void* stream) {
+    MPN_CHECK_ARG(dst && n > 0);
+    hipLaunchKernelGGL(fill_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, dst, v, (long)n);
+    return mpn_launch_status();
+}
+
+extern "C" const char* mpn_version(void) { return "mpn-hip 0.1 (gfx950)"; }
