@@ -151,6 +151,7 @@ int mpn_nchw_to_nhwc_f32(const float* src, int64_t sB, int64_t sC, int64_t sH, i
  * (the permute+view+cat of network/posenet.py:67-69,111-117,327-328 without any copy kernels in between) */
 int mpn_det_pack(const void* src, int src_dtype, float* dst, int B, int64_t HW, int Cs, int C, int64_t dst_sB, void* stream);
 int mpn_det_unpack(const float* ddst, void* dsrc, int dst_dtype, int B, int64_t HW, int Cs, int C, int64_t dst_sB, void* stream);
+int mpn_relu_forward(const void* x, void* y, int64_t n, int dtype, void* stream);
 int mpn_relu_backward(const void* dz, const void* z, void* dx, int64_t n, int accumulate, int dtype, void* stream);
 int mpn_add_inplace(void* dst, const void* src, int64_t n, int dtype, void* stream);
 int mpn_channel_sum(const void* dy, int dy_dtype, int64_t P, int C, int Cs, float* partial, int chunks, void* stream);
@@ -173,6 +174,7 @@ int mpn_mse_chunks(int64_t npix);
 int mpn_focal_blocks(int A);   /* partial needs B * mpn_focal_blocks(A) * 4 floats */
 int mpn_focal_forward(const float* cls, const float* reg, const float* anchors, const float* anno,
                       int B, int A, int maxN, float* partial, float* per_img, float* out, void* stream);
+/* gscale: device float[2] = upstream gradients of {cls loss, reg loss} */
 int mpn_focal_backward(const float* cls, const float* reg, const float* anchors, const float* anno,
                        int B, int A, int maxN, const float* per_img, const float* gscale,
                        float* dcls, float* dreg, void* stream);

@@ -229,7 +229,8 @@ __global__ void focal_bwd_kernel(const float* __restrict__ cls, const float* __r
     const int b = blockIdx.y;
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= A) return;
-    const float gs = gscale ? gscale[0] : 1.f;
+    const float gs = gscale ? gscale[0] : 1.f;        // upstream grad of the classification loss
+    const float gsr = gscale ? gscale[1] : 1.f;       // upstream grad of the regression loss
     const float* an = anno + (long)b * maxN * 5;
     const float npos = per_img[b * 4 + 2], nvalid = per_img[b * 4 + 3];
     float dc = 0.f;
@@ -247,7 +248,7 @@ __global__ void focal_bwd_kernel(const float* __restrict__ cls, const float* __r
             float t[4]; reg_targets(box, an + as.arg * 5, t);
             const float4 r = *reinterpret_cast<const float4*>(reg + ((long)b * A + a) * 4);
             const float rr[4] = {r.x, r.y, r.z, r.w};
-            const float kr = gs / ((float)B * 4.f * npos);
+            const float kr = gsr / ((float)B * 4.f * npos);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float e = rr[k] - t[k];

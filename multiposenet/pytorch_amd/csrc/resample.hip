@@ -222,6 +222,17 @@ __global__ void relu_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ 
 }
 
 template <typename T>
+__global__ void relu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long nvec) {
+    constexpr int V = Vec16<T>::N;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvec) return;
+    Vec16<T> a; a.load(x + i * V);
+#pragma unroll
+    for (int k = 0; k < V; ++k) a.v[k] = fmaxf(a.v[k], 0.f);
+    a.store(y + i * V);
+}
+
+template <typename T>
 __global__ void add_inplace_kernel(T* __restrict__ dst, const T* __restrict__ src, long nvec) {
     constexpr int V = Vec16<T>::N;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -358,6 +369,15 @@ extern "C" int mpn_relu_backward(const void* dz, const void* z, void* dx, int64_
     const long nvec = n / V;
     if (dtype == MPN_F32) hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(nb(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)dz, (const float*)z, (float*)dx, nvec, accumulate);
     else hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(nb(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz, (const bf16_t*)z, (bf16_t*)dx, nvec, accumulate);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_relu_forward(const void* x, void* y, int64_t n, int dtype, void* stream) {
+    MPN_CHECK_ARG(x && y && n > 0 && n % 8 == 0);
+    const int V = dtype == MPN_F32 ? 4 : 8;
+    const long nvec = n / V;
+    if (dtype == MPN_F32) hipLaunchKernelGGL(relu_fwd_kernel<float>, dim3(nb(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, nvec);
+    else hipLaunchKernelGGL(relu_fwd_kernel<bf16_t>, dim3(nb(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, nvec);
     return mpn_launch_status();
 }
 

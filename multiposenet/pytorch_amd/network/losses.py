@@ -1,0 +1,147 @@
+"""Loss layer of the hot path — same names and return structure as the reference
+(``network/losses.py`` FocalLoss / calc_iou, ``network/posenet.py:367-445`` build_*_loss), computed
+by fused HIP kernels (csrc/losses.hip) instead of per-image python loops and ~60 tiny ATen kernels.
+"""
+import ctypes
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import call
+
+_i64x5 = ctypes.c_int64 * 5
+_i32x5 = ctypes.c_int32 * 5
+_vpx5 = ctypes.c_void_p * 5
+
+
+def _pixel_major(t):
+    """logical [B,C,H,W] f32 -> [B,H,W,C] view with unit channel stride and row-major pixels."""
+    g = t.permute(0, 2, 3, 1)
+    if g.dtype != torch.float32:
+        g = g.float()
+    if g.stride(3) != 1 or g.stride(1) != g.shape[2] * g.stride(2) or g.stride(0) != g.shape[1] * g.stride(1):
+        g = g.contiguous()
+    return g
+
+
+class _HeatmapMSE(torch.autograd.Function):
+    """sum_j mean(((pred_j[:, :18] * w) - (w * gt))^2)   (posenet.py:376-387)."""
+
+    @staticmethod
+    def forward(ctx, heat_nhwc, wgt_nhwc, *preds):
+        pm = [_pixel_major(p.detach()) for p in preds]
+        B, H, W, _ = pm[0].shape
+        npix = B * H * W
+        dev = pm[0].device
+        chunks = call("mpn_mse_chunks", npix)
+        part = ops.workspace(chunks * 8 * 4, dev, slot=5)
+        out = torch.empty(8, dtype=torch.float32, device=dev)
+        call("mpn_mse_heatmap_forward", _vpx5(*[p.data_ptr() for p in pm]), _i64x5(*[p.stride(2) for p in pm]),
+             ops.ptr(heat_nhwc), ops.ptr(wgt_nhwc), npix, ops.ptr(part), chunks, ops.ptr(out), ops.stream_ptr())
+        ctx.pm = pm
+        ctx.gt = (heat_nhwc, wgt_nhwc)
+        ctx.mark_non_differentiable(out)
+        return out[5].clone(), out
+
+    @staticmethod
+    def backward(ctx, gtotal, _gout):
+        pm = ctx.pm
+        heat, wgt = ctx.gt
+        B, H, W, _ = pm[0].shape
+        npix = B * H * W
+        grads, gptr, gsp, gc = [], [], [], []
+        for j, p in enumerate(pm):
+            if ctx.needs_input_grad[2 + j]:
+                g = torch.empty((B, H, W, p.shape[3]), dtype=torch.float32, device=p.device)
+                grads.append(g.permute(0, 3, 1, 2))
+                gptr.append(g.data_ptr()); gsp.append(g.stride(2)); gc.append(p.shape[3])
+            else:
+                grads.append(None)
+                gptr.append(None); gsp.append(0); gc.append(0)
+        gs = gtotal.detach().reshape(1).float().contiguous()
+        call("mpn_mse_heatmap_backward", _vpx5(*[p.data_ptr() for p in pm]), _vpx5(*gptr), _i64x5(*[p.stride(2) for p in pm]),
+             _i64x5(*gsp), _i32x5(*gc), ops.ptr(heat), ops.ptr(wgt), npix, ops.ptr(gs), ops.stream_ptr())
+        return (None, None) + tuple(grads)
+
+
+def build_names():
+    names = []
+    for j in range(2, 6):
+        names.append('heatmap_loss_k%d' % j)
+        names.append('seg_loss_k%d' % j)
+    names.append('heatmap_loss')
+    names.append('seg_loss')
+    return names
+
+
+def build_keypoint_loss(saved_for_loss, heat_temp, heat_weight):
+    """posenet.py:367-403: returns (total_loss tensor with grad, OrderedDict of floats)."""
+    names = build_names()
+    heat = ops.nchw_to_nhwc_f32(heat_temp.detach().float())
+    wgt = ops.nchw_to_nhwc_f32(heat_weight.detach().float())
+    total, out = _HeatmapMSE.apply(heat, wgt, *saved_for_loss[:5])
+    vals = out.cpu().tolist()       # one D2H copy instead of the reference's seven .item() syncs
+    log = OrderedDict()
+    for j in range(5):
+        log[names[j * 2]] = vals[j]
+    log['max_ht'] = vals[6]
+    log['min_ht'] = vals[7]
+    return total, log
+
+
+class _Focal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cls, reg, anchors, anno):
+        B, A = cls.shape[0], cls.shape[1]
+        if cls.shape[2] != 1:
+            raise NotImplementedError("the hot path is single-class (posenet.py:189 num_classes=1)")
+        dev = cls.device
+        c = cls.detach().float().contiguous()
+        r = reg.detach().float().contiguous()
+        an = anchors.detach().float().reshape(-1, 4).contiguous()
+        ann = anno.detach().float().contiguous()
+        maxn = ann.shape[1]
+        blocks = call("mpn_focal_blocks", A)
+        part = ops.workspace(B * blocks * 4 * 4, dev, slot=6)
+        per_img = torch.empty((B, 4), dtype=torch.float32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        call("mpn_focal_forward", ops.ptr(c), ops.ptr(r), ops.ptr(an), ops.ptr(ann), B, A, maxn, ops.ptr(part), ops.ptr(per_img),
+             ops.ptr(out), ops.stream_ptr())
+        ctx.saved = (c, r, an, ann, per_img)
+        return out[0:1].clone(), out[1:2].clone()
+
+    @staticmethod
+    def backward(ctx, gc, gr):
+        c, r, an, ann, per_img = ctx.saved
+        B, A = c.shape[0], c.shape[1]
+        dev = c.device
+        dcls = torch.empty((B, A, 1), dtype=torch.float32, device=dev)
+        dreg = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
+        gs = torch.empty(2, dtype=torch.float32, device=dev)      # {d/d cls_loss, d/d reg_loss}
+        gs[0:1].copy_(gc.detach().reshape(1))
+        gs[1:2].copy_(gr.detach().reshape(1))
+        call("mpn_focal_backward", ops.ptr(c), ops.ptr(r), ops.ptr(an), ops.ptr(ann), B, A, ann.shape[1], ops.ptr(per_img),
+             ops.ptr(gs), ops.ptr(dcls), ops.ptr(dreg), ops.stream_ptr())
+        return dcls, dreg, None, None
+
+
+class FocalLoss(nn.Module):
+    """network/losses.py:24-137: forward(classifications, regressions, anchors, annotations)
+    -> (classification_loss[1], regression_loss[1]) batch means."""
+
+    def forward(self, classifications, regressions, anchors, annotations):
+        return _Focal.apply(classifications, regressions, anchors, annotations)
+
+
+def build_detection_loss(saved_for_loss, anno):
+    """posenet.py:405-425."""
+    log = OrderedDict()
+    closs, rloss = FocalLoss()(*saved_for_loss, anno)
+    closs = closs.mean()
+    rloss = rloss.mean()
+    total = closs + rloss
+    vals = torch.stack([total.detach(), closs.detach(), rloss.detach()]).cpu().tolist()
+    log['total_loss'], log['classification_loss'], log['regression_loss'] = vals
+    return total, log

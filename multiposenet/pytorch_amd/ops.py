@@ -1,0 +1,350 @@
+"""Tensor-level wrappers over the C-ABI (``include/mpn.h``).
+
+torch is used only as the device-memory allocator and stream provider: every function here passes
+raw device pointers, sizes and the current ``hipStream_t`` to ``libmpn_hip.so``.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, ConvParams, WgradParams, call
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise _lib.MpnError("unsupported dtype %s" % dt)
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Act(object):
+    """Dense pixel-major activation: storage ``t`` is [B, H, W, Cs] contiguous, ``C`` logical channels.
+
+    Cs (channel storage) is a multiple of 32; lanes [C, Cs) hold zeros (see include/mpn.h).
+    """
+    __slots__ = ("t", "B", "H", "W", "C", "Cs", "needs_grad", "tag")
+
+    def __init__(self, t, C, needs_grad=False, tag=""):
+        self.t = t
+        self.B, self.H, self.W, self.Cs = t.shape
+        self.C = C
+        self.needs_grad = needs_grad
+        self.tag = tag
+
+    @staticmethod
+    def empty(B, H, W, C, dtype, device, needs_grad=False, tag=""):
+        return Act(torch.empty((B, H, W, round_up(C, 32)), dtype=dtype, device=device), C, needs_grad, tag)
+
+    @property
+    def P(self):
+        return self.B * self.H * self.W
+
+    @property
+    def dtype(self):
+        return self.t.dtype
+
+    def nchw(self):
+        """Logical [B, C, H, W] view (channels_last strides) — the shape the reference API exposes."""
+        return self.t[..., : self.C].permute(0, 3, 1, 2)
+
+
+_ws = {}
+
+
+def workspace(nbytes, device, slot=0):
+    """Persistent scratch (grown geometrically); one buffer per (device, slot)."""
+    key = (str(device), slot)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def conv_out_hw(H, W, R, S, stride, pad):
+    return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+
+
+def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, res=None, res_mode=0,
+                 want_stats=False, out_f32=False, out=None, accumulate=False, mode=0, out_hw=None,
+                 cin=None, x_geom=None, y_geom=None, cout_store=None, needs_grad=False, tag=""):
+    """Implicit-GEMM convolution.  x: Act.  w: compute-dtype tensor laid out [Cout][R][S][Cin].
+
+    mode 0 = forward gather, mode 1 = dgrad gather (then ``out_hw`` is the input-gradient size and
+    ``w`` is the transposed copy).  x_geom=(H, W, sB, sH, sW) overrides the source geometry (stem).
+    y_geom=(ptr_tensor, sB, sP) writes into a slice of a larger buffer.  Returns (Act|None, stats).
+    """
+    dev = x.t.device
+    dt = x.t.dtype
+    Cin = cin if cin is not None else round_up(x.C, 32 if dt == torch.bfloat16 else 16)
+    if x_geom is None:
+        H, W = x.H, x.W
+        sB, sH, sW = x.H * x.W * x.Cs, x.W * x.Cs, x.Cs
+    else:
+        H, W, sB, sH, sW = x_geom
+    if out_hw is None:
+        Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    else:
+        Ho, Wo = out_hw
+    odt = torch.float32 if out_f32 else dt
+    p = ConvParams()
+    if y_geom is None:
+        if out is None:
+            out = Act.empty(x.B, Ho, Wo, Cout, odt, dev, needs_grad, tag)
+        assert out.t.dtype == odt and (out.B, out.H, out.W) == (x.B, Ho, Wo), "conv output geometry mismatch"
+        p.y = out.t.data_ptr()
+        p.y_sB, p.y_sP = Ho * Wo * out.Cs, out.Cs
+        p.Cout_store = out.Cs if cout_store is None else cout_store
+    else:
+        yt, ysB, ysP = y_geom
+        p.y = yt.data_ptr()
+        p.y_sB, p.y_sP = ysB, ysP
+        p.Cout_store = cout_store if cout_store is not None else round_up(Cout, 4)
+    p.x = x.t.data_ptr()
+    p.w = w.data_ptr()
+    p.bias = bias.data_ptr() if bias is not None else None
+    p.scale = scale.data_ptr() if scale is not None else None
+    p.x_sB, p.x_sH, p.x_sW = sB, sH, sW
+    p.B, p.H, p.W, p.Cin = x.B, H, W, Cin
+    p.Ho, p.Wo, p.Cout = Ho, Wo, Cout
+    p.R, p.S, p.stride, p.pad = R, S, stride, pad
+    p.mode, p.act, p.accumulate = mode, act, 1 if accumulate else 0
+    p.dtype = dtype_code(dt)
+    p.out_f32 = 1 if (out_f32 and dt != torch.float32) else 0
+    if res is not None:
+        assert res.t.dtype == odt
+        p.res = res.t.data_ptr()
+        p.res_mode = res_mode
+        p.res_sB, p.res_sP = res.H * res.W * res.Cs, res.Cs
+        p.res_H, p.res_W = res.H, res.W
+    stats = None
+    if want_stats:
+        tiles = call("mpn_conv_stats_tiles", ctypes.byref(p))
+        stats = torch.empty((tiles, Cout, 2), dtype=torch.float32, device=dev)
+        p.stats = stats.data_ptr()
+    call("mpn_conv_forward", ctypes.byref(p), stream_ptr())
+    return out, stats
+
+
+def conv_wgrad(x, dy, dw, Cout, R, S, stride, pad, cin=None, x_geom=None):
+    """dw (f32 view laid out [Cout][R][S][Cin], contiguous) += wgrad(x, dy)."""
+    dev = x.t.device
+    dt = x.t.dtype
+    p = WgradParams()
+    if x_geom is None:
+        H, W = x.H, x.W
+        sB, sH, sW = x.H * x.W * x.Cs, x.W * x.Cs, x.Cs
+        Cin = cin if cin is not None else x.C
+    else:
+        H, W, sB, sH, sW = x_geom
+        Cin = cin
+    p.x, p.dy, p.dw = x.t.data_ptr(), dy.t.data_ptr(), dw.data_ptr()
+    p.x_sB, p.x_sH, p.x_sW = sB, sH, sW
+    p.dy_sP = dy.Cs
+    p.B, p.H, p.W, p.Cin = x.B, H, W, Cin
+    p.Ho, p.Wo, p.Cout = dy.H, dy.W, Cout
+    p.R, p.S, p.stride, p.pad = R, S, stride, pad
+    p.dtype = dtype_code(dt)
+    p.chunks = 1
+    chunks = call("mpn_conv_wgrad_chunks", ctypes.byref(p))
+    p.chunks = chunks
+    if chunks > 1:
+        ws = workspace(chunks * Cout * R * S * Cin * 4, dev, slot=1)
+        p.ws = ws.data_ptr()
+    call("mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
+
+
+def bias_grad(dy, db, C):
+    """db[C] (f32) += column sums of dy."""
+    chunks = call("mpn_channel_sum_chunks", dy.P, C)
+    ws = workspace(chunks * C * 4, dy.t.device, slot=2)
+    call("mpn_channel_sum", ptr(dy.t), dtype_code(dy.t.dtype), dy.P, C, dy.Cs, ptr(ws), chunks, stream_ptr())
+    call("mpn_reduce_partials", ptr(ws), chunks, C, ptr(db), 1, stream_ptr())
+
+
+def weight_transpose(w_master, wt, Cout, RS, Cin, Cout_pad):
+    call("mpn_weight_transpose", ptr(w_master), ptr(wt), Cout, RS, Cin, Cout_pad, dtype_code(wt.dtype), stream_ptr())
+
+
+def cast_bf16(src, dst):
+    call("mpn_cast_f32_to_bf16", ptr(src), ptr(dst), src.numel(), stream_ptr())
+
+
+class BNState(object):
+    __slots__ = ("mean", "invstd", "scale", "shift")
+
+    def __init__(self, C, device):
+        buf = torch.empty((4, C), dtype=torch.float32, device=device)
+        self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
+
+
+def bn_finalize_train(stats, count, gamma, beta, rm, rv, momentum=0.1, eps=1e-5):
+    C = stats.shape[1]
+    st = BNState(C, stats.device)
+    call("mpn_bn_finalize_train", ptr(stats), stats.shape[0], C, count, ptr(gamma), ptr(beta), ptr(rm), ptr(rv),
+         momentum, eps, ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), stream_ptr())
+    return st
+
+
+def bn_finalize_eval(gamma, beta, rm, rv, eps=1e-5):
+    C = gamma.numel()
+    st = BNState(C, gamma.device)
+    call("mpn_bn_finalize_eval", C, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), eps, ptr(st.mean), ptr(st.invstd),
+         ptr(st.scale), ptr(st.shift), stream_ptr())
+    return st
+
+
+def bn_act(y, st, relu, res=None, needs_grad=False, tag=""):
+    z = Act(torch.empty_like(y.t), y.C, needs_grad, tag)
+    call("mpn_bn_act_forward", ptr(y.t), ptr(res.t) if res is not None else None, ptr(z.t), ptr(st.scale), ptr(st.shift),
+         y.P, y.C, y.Cs, 1 if relu else 0, dtype_code(y.t.dtype), stream_ptr())
+    return z
+
+
+def bn_backward(dz, z, y, st, gamma, relu, train, dgamma=None, dbeta=None, want_dy=True, dres=None, dres_acc=False):
+    """Returns dy (Act or None).  dres (Act) receives/accumulates g = dz*(z>0)."""
+    dev = y.t.device
+    P, C, Cs = y.P, y.C, y.Cs
+    dc = dtype_code(y.t.dtype)
+    coef = None
+    if train or dgamma is not None or dbeta is not None:
+        chunks = call("mpn_bn_bwd_chunks", P, C)
+        part = workspace(chunks * C * 2 * 4, dev, slot=3)
+        call("mpn_bn_bwd_reduce", ptr(dz.t), ptr(z.t) if relu else None, ptr(y.t), ptr(st.mean), ptr(st.invstd), ptr(part),
+             chunks, P, C, Cs, 1 if relu else 0, dc, stream_ptr())
+        if train:
+            coef = torch.empty((C, 2), dtype=torch.float32, device=dev)
+        call("mpn_bn_bwd_finalize", ptr(part), chunks, C, P, ptr(dgamma), ptr(dbeta), ptr(coef), stream_ptr())
+    dy = None
+    if want_dy or dres is not None:
+        if want_dy:
+            dy = Act(torch.empty_like(y.t), C)
+        call("mpn_bn_bwd_apply", ptr(dz.t), ptr(z.t) if relu else None, ptr(y.t), ptr(st.mean), ptr(st.invstd), ptr(gamma),
+             ptr(coef), ptr(dy.t) if dy is not None else None, ptr(dres.t) if dres is not None else None,
+             1 if dres_acc else 0, P, C, Cs, 1 if relu else 0, dc, stream_ptr())
+    return dy
+
+
+def maxpool_forward(x, needs_grad=False):
+    Ho, Wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
+    y = Act(torch.empty((x.B, Ho, Wo, x.Cs), dtype=x.t.dtype, device=x.t.device), x.C, needs_grad)
+    idx = torch.empty((x.B, Ho, Wo, x.Cs), dtype=torch.uint8, device=x.t.device) if needs_grad else None
+    call("mpn_maxpool3x3s2_forward", ptr(x.t), ptr(y.t), ptr(idx), x.B, x.H, x.W, x.Cs, Ho, Wo, dtype_code(x.t.dtype), stream_ptr())
+    return y, idx
+
+
+def maxpool_backward(dy, idx, x_like):
+    dx = Act(torch.empty_like(x_like.t), x_like.C)
+    call("mpn_maxpool3x3s2_backward", ptr(dy.t), ptr(idx), ptr(dx.t), x_like.B, x_like.H, x_like.W, x_like.Cs, dy.H, dy.W,
+         dtype_code(dy.t.dtype), stream_ptr())
+    return dx
+
+
+def upsample_backward(dfine, dcoarse, accumulate):
+    call("mpn_upsample_nearest_backward", ptr(dfine.t), ptr(dcoarse.t), dfine.B, dfine.H, dfine.W, dcoarse.H, dcoarse.W,
+         dfine.Cs, 1 if accumulate else 0, dtype_code(dfine.t.dtype), stream_ptr())
+
+
+def upsample_slice(src, dst, c_off):
+    call("mpn_upsample_nearest_slice", ptr(src.t), ptr(dst.t), src.B, src.H, src.W, src.Cs, dst.H, dst.W, dst.Cs, c_off,
+         dtype_code(src.t.dtype), stream_ptr())
+
+
+def upsample_slice_backward(ddst, dsrc, c_off):
+    call("mpn_upsample_nearest_slice_backward", ptr(ddst.t), ptr(dsrc.t), dsrc.B, dsrc.H, dsrc.W, dsrc.Cs, ddst.H, ddst.W,
+         ddst.Cs, c_off, dtype_code(dsrc.t.dtype), stream_ptr())
+
+
+def export_f32(src, C, Ho, Wo):
+    """Internal padded [B,h,w,Cs] -> exact f32 tensor of logical shape [B,C,Ho,Wo] (channels_last)."""
+    out = torch.empty((src.B, Ho, Wo, C), dtype=torch.float32, device=src.t.device)
+    call("mpn_export_f32", ptr(src.t), dtype_code(src.t.dtype), ptr(out), src.B, src.H, src.W, src.Cs, C, Ho, Wo,
+         Ho * Wo * C, C, stream_ptr())
+    return out.permute(0, 3, 1, 2)
+
+
+def import_grad(g_nchw, like, dtype):
+    """f32 gradient w.r.t. an exported tensor (logical [B,C,Ho,Wo], any strides w/ channel stride 1
+    after permute) -> internal padded gradient Act shaped like ``like`` (sums nearest children)."""
+    B, C, Ho, Wo = g_nchw.shape
+    g = g_nchw.permute(0, 2, 3, 1)
+    if g.stride(3) != 1 or g.stride(1) != Wo * g.stride(2):
+        g = g.contiguous()
+    d = Act(torch.empty((like.B, like.H, like.W, like.Cs), dtype=dtype, device=like.t.device), like.C)
+    call("mpn_import_grad", ptr(g), g.stride(0), g.stride(2), ptr(d.t), dtype_code(dtype), like.B, like.H, like.W, like.Cs,
+         like.C, Ho, Wo, stream_ptr())
+    return d
+
+
+def relu_forward(x, needs_grad=False):
+    y = Act(torch.empty_like(x.t), x.C, needs_grad)
+    call("mpn_relu_forward", ptr(x.t), ptr(y.t), x.t.numel(), dtype_code(x.t.dtype), stream_ptr())
+    return y
+
+
+def relu_backward(dz, z, dx=None, accumulate=False):
+    if dx is None:
+        dx = Act(torch.empty_like(z.t), z.C)
+        accumulate = False
+    call("mpn_relu_backward", ptr(dz.t), ptr(z.t), ptr(dx.t), z.t.numel(), 1 if accumulate else 0, dtype_code(z.t.dtype), stream_ptr())
+    return dx
+
+
+def add_inplace(dst, src):
+    call("mpn_add_inplace", ptr(dst.t), ptr(src.t), dst.t.numel(), dtype_code(dst.t.dtype), stream_ptr())
+
+
+def nchw_to_nhwc_f32(t):
+    """Arbitrary-strided f32 [B,C,H,W] -> dense [B,H,W,C] f32."""
+    B, C, H, W = t.shape
+    out = torch.empty((B, H, W, C), dtype=torch.float32, device=t.device)
+    call("mpn_nchw_to_nhwc_f32", ptr(t), t.stride(0), t.stride(1), t.stride(2), t.stride(3), ptr(out), B, C, H, W, stream_ptr())
+    return out
+
+
+def nms(dets, thresh, mode=0):
+    """dets: f32 [N,5] device tensor.  Returns int64 device tensor of kept ORIGINAL indices (one D2H of the count)."""
+    n = dets.shape[0]
+    dev = dets.device
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=dev)
+    dets = dets.contiguous()
+    keep = torch.empty((n,), dtype=torch.int64, device=dev)
+    num = torch.empty((1,), dtype=torch.int64, device=dev)
+    ws = workspace(call("mpn_nms_workspace_bytes", n), dev, slot=4)
+    call("mpn_nms", ptr(dets), n, float(thresh), mode, ptr(keep), ptr(num), ptr(ws), stream_ptr())
+    k = int(num.item())
+    return keep[:k]
+
+
+def box_decode_clip(anchors, deltas, img_w, img_h):
+    B, A, _ = deltas.shape
+    boxes = torch.empty((B, A, 4), dtype=torch.float32, device=deltas.device)
+    call("mpn_box_decode_clip", ptr(anchors), ptr(deltas), ptr(boxes), B, A, float(img_w), float(img_h), stream_ptr())
+    return boxes
+
+
+def score_filter(boxes0, scores0, thresh):
+    """Image-0 candidates with score > thresh: returns (dets[n,5], src_idx[n]) (one D2H of n)."""
+    A = scores0.numel()
+    dev = scores0.device
+    dets = torch.empty((A, 5), dtype=torch.float32, device=dev)
+    src = torch.empty((A,), dtype=torch.int32, device=dev)
+    cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+    call("mpn_score_filter", ptr(boxes0), ptr(scores0), A, float(thresh), ptr(dets), ptr(src), ptr(cnt), stream_ptr())
+    n = int(cnt.item())
+    return dets[:n], src[:n]
