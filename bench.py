@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py — images/sec of the MultiPoseNet training step (fwd + losses + bwd + Adam) on MI355X.
+
+Workload (BASELINE.json metric / SURVEY.md 8d cfg3): ResNet-101 full posenet (shared backbone, both
+pyramids, keypoint head + heat-map MSE, RetinaNet heads + focal/smooth-L1), 480x480, 32 images/GPU,
+bf16 MFMA arithmetic with fp32 accumulation and fp32 master weights, synthetic COCO-shaped batches
+resident in HBM.  One process per GPU; N>1 = data parallel (RCCL all-reduce of the flat gradient
+arena overlapped with backward); weak scaling (32 images per GPU).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the 128x128 bf16 implicit-GEMM
+conv tile), timed live with HIP events on the launch stream during the timed steps; `cpu_baseline`
+is the oracle's torch-CPU restatement of the same step timed on this host (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+GFLOP_PER_IMG_TRAIN = {("r101", 480): 608.6, ("r50", 480): 343.7}    # BASELINE.md section 3 (algorithmic, 3 x fwd)
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--size", type=int, default=480)
+    ap.add_argument("--layers", type=int, default=101)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    return ap.parse_args()
+
+
+def synth(batch, size, device, seed):
+    from oracle import weightgen          # data generator only (deterministic Philox), not arithmetic
+    img = torch.from_numpy(weightgen.gen_images(seed, batch, size, size))
+    heat, wgt = weightgen.gen_keypoint_gt(seed, batch, size // 4, size // 4)
+    anno = torch.from_numpy(weightgen.gen_boxes_gt(seed, batch, size, max_n=8))
+    return img.to(device), torch.from_numpy(heat).to(device), torch.from_numpy(wgt).to(device), anno.to(device)
+
+
+def he_weights(model):
+    from oracle import weightgen
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = weightgen.gen_state_dict(shapes, seed=0, flavour="he", skip_prefixes=("prn.",))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    return sd
+
+
+def cpu_baseline(args, sd):
+    """The oracle's CPU restatement of the same step (fwd + both losses + bwd + Adam), all host cores."""
+    from oracle import posenet_oracle as po, weightgen
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B, S = args.cpu_batch, args.size
+    params = {k: torch.from_numpy(v).clone() for k, v in sd.items() if v.dtype != np.int64}
+    leaves = []
+    for k, v in params.items():
+        if not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+            leaves.append(v)
+    opt = torch.optim.Adam(leaves, lr=1e-4)
+    img = torch.from_numpy(weightgen.gen_images(1, B, S, S))
+    heat, wgt = weightgen.gen_keypoint_gt(1, B, S // 4, S // 4)
+    anno = torch.from_numpy(weightgen.gen_boxes_gt(1, B, S, max_n=8))
+
+    def step():
+        pred, (ks, ds) = po.posenet_forward(params, img, "train_both", args.layers, True)
+        l1, _ = po.keypoint_loss(ks, torch.from_numpy(heat), torch.from_numpy(wgt))
+        l2, _ = po.detection_loss(ds, anno)
+        opt.zero_grad()
+        (l1 + l2).backward()
+        opt.step()
+    step()                      # warm-up (oneDNN primitive creation)
+    t0 = time.time()
+    n = 0
+    while True:
+        step()
+        n += 1
+        if time.time() - t0 > 12.0 or n >= 3:
+            break
+    dt = (time.time() - t0) / n
+    return {"value": round(B / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "oracle torch-CPU restatement, R%d train_both %dx%d, batch %d, %d step(s) of fwd+loss+bwd+Adam, fp32"
+                      % (args.layers, S, S, B, n)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    from multiposenet.pytorch_amd import ddp, ops
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    from multiposenet.pytorch_amd.optim import FusedAdam
+
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = poseNet(args.layers, compute_dtype=cdt).to(dev)
+    sd = he_weights(model)
+    for p in model.prn.parameters():          # PRN is not part of this step (all non-PRN params trainable)
+        p.requires_grad = False
+    model.train()
+    if world > 1:
+        ddp.attach(model, bucket_mb=32.0)
+    opt = FusedAdam(model, lr=1e-4, weight_decay=0.0)
+    img, heat, wgt, anno = synth(args.batch, args.size, dev, seed=100 + rank)
+
+    def step():
+        pred, (ks, ds) = model([img, "train_both"])
+        loss, log = poseNet.build_loss((ks, ds), "train_both", heat, wgt, anno)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_kernel_events:
+        ops.KERNEL_EVENTS.enable()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.KERNEL_EVENTS.disable()
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(loss).all()
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1000.0
+        ips = args.batch * world * args.steps / elapsed
+        out = {
+            "metric": "images/sec (train fwd+bwd) ResNet101 480x480 bs=32/GPU",
+            "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "R%d full posenet (keypoint+detection) train step: fwd + MSE/focal losses + bwd + Adam, "
+                                   "%dx%d, %d images/GPU, %s MFMA / fp32 accumulate / fp32 master weights"
+                                   % (args.layers, args.size, args.size, args.batch, args.dtype),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+        }
+        gf = GFLOP_PER_IMG_TRAIN.get(("r%d" % args.layers, args.size))
+        if gf is not None:
+            out["model_tflops_per_gpu"] = round(ips / world * gf / 1000.0, 2)
+        ke = ops.KERNEL_EVENTS.summary()
+        if ke:
+            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+            dom = max(ke.items(), key=lambda kv: kv[1]["ms"])
+            name, d = dom
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4), "traffic": None, "launches": d["n"],
+                               "avg_launch_us": round(d["ms"] * 1000.0 / max(d["n"], 1), 2),
+                               "share_of_step": round(d["ms"] / (ms * args.steps), 4)}
+            out["kernel_classes_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(ke.items(), key=lambda kv: -kv[1]["ms"])}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, sd)
+            except Exception as e:      # the baseline is a reported side figure; never lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -178,6 +178,7 @@ int mpn_focal_forward(const float* cls, const float* reg, const float* anchors, 
 int mpn_focal_backward(const float* cls, const float* reg, const float* anchors, const float* anno,
                        int B, int A, int maxN, const float* per_img, const float* gscale,
                        float* dcls, float* dreg, void* stream);
+int mpn_sigmoid_forward(const float* x, float* y, int64_t n, void* stream);   /* in place allowed */
 /* dlogit = dp * p * (1-p) */
 int mpn_sigmoid_backward(const float* dp, const float* p, float* dlogit, int64_t n, void* stream);
 /* PRN: out = softmax(a + res) rowwise (posenet.py:345-347); BCE mean (posenet.py:436-439) */
@@ -188,12 +189,17 @@ int mpn_bce_mean_forward(const float* p, const float* label, int64_t n, float* p
 /* ---------------------------------------------------------------------------------------------
  * Boxes (network/utils.py:19-61, network/posenet.py:266-271)
  * -------------------------------------------------------------------------------------------*/
+/* img_w < 0 disables the clip (pure BBoxTransform) */
 int mpn_box_decode_clip(const float* anchors, const float* deltas, float* boxes, int B, int A,
                         float img_w, float img_h, void* stream);
+int mpn_clip_boxes(float* boxes, int64_t n, float img_w, float img_h, void* stream);   /* in place, utils.py:55-59 */
 /* compact image-0 candidates with score > thresh into dets[n,5] (x1,y1,x2,y2,score) + src index;
  * order preserved (ascending anchor index).  count[0] receives n. */
 int mpn_score_filter(const float* boxes, const float* scores, int A, float thresh, float* dets,
                      int32_t* src_idx, int32_t* count, void* stream);
+
+/* boxes[k,4], scores[k] = rows keep[0..k) of dets[n,5] */
+int mpn_gather_dets(const float* dets, const int64_t* keep, int k, float* boxes, float* scores, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * NMS — replaces lib/nms: gpu_nms (src/nms_cuda.c:17-67), _nms/nms_kernel

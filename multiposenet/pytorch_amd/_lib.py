@@ -95,11 +95,14 @@ SIGNATURES = {
     "mpn_focal_blocks": (_i, [_i]),
     "mpn_focal_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mpn_focal_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "mpn_sigmoid_forward": (_i, [_vp, _vp, _i64, _vp]),
+    "mpn_gather_dets": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "mpn_sigmoid_backward": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "mpn_add_softmax_rows": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "mpn_bce_chunks": (_i, [_i64]),
     "mpn_bce_mean_forward": (_i, [_vp, _vp, _i64, _vp, _i, _vp, _vp]),
     "mpn_box_decode_clip": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),
+    "mpn_clip_boxes": (_i, [_vp, _i64, _f, _f, _vp]),
     "mpn_score_filter": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "mpn_nms_workspace_bytes": (_i64, [_i64]),
     "mpn_nms": (_i, [_vp, _i64, _f, _i, _vp, _vp, _vp, _vp]),

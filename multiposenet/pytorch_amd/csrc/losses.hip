@@ -268,6 +268,11 @@ __global__ void sigmoid_bwd_kernel(const float* __restrict__ dp, const float* __
     if (i < n) { const float pv = p[i]; dl[i] = dp[i] * pv * (1.f - pv); }
 }
 
+__global__ void sigmoid_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = 1.0f / (1.0f + expf(-x[i]));
+}
+
 // ------------------------------------------------------------------------------- PRN pieces
 __global__ void add_softmax_rows_kernel(const float* __restrict__ a, const float* __restrict__ res, float* __restrict__ out, int cols) {
     __shared__ float sh[4];
@@ -372,6 +377,12 @@ extern "C" int mpn_focal_backward(const float* cls, const float* reg, const floa
 extern "C" int mpn_sigmoid_backward(const float* dp, const float* p, float* dlogit, int64_t n, void* stream) {
     MPN_CHECK_ARG(dp && p && dlogit && n > 0);
     hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dp, p, dlogit, (long)n);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_sigmoid_forward(const float* x, float* y, int64_t n, void* stream) {
+    MPN_CHECK_ARG(x && y && n > 0);
+    hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n);
     return mpn_launch_status();
 }
 

@@ -38,8 +38,16 @@ __global__ void box_decode_clip_kernel(const float* __restrict__ anchors, const 
     const float pw = expf(dw) * w, ph = expf(dh) * h;
     float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
     // utils.py:55-59
-    x1 = fmaxf(x1, 0.f); y1 = fmaxf(y1, 0.f); x2 = fminf(x2, img_w); y2 = fminf(y2, img_h);
+    if (img_w >= 0.f) { x1 = fmaxf(x1, 0.f); y1 = fmaxf(y1, 0.f); x2 = fminf(x2, img_w); y2 = fminf(y2, img_h); }
     *reinterpret_cast<float4*>(boxes + i * 4) = make_float4(x1, y1, x2, y2);
+}
+
+__global__ void clip_boxes_kernel(float* __restrict__ boxes, long n, float img_w, float img_h) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 b = *reinterpret_cast<float4*>(boxes + i * 4);
+    b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fminf(b.z, img_w); b.w = fminf(b.w, img_h);
+    *reinterpret_cast<float4*>(boxes + i * 4) = b;
 }
 
 // single workgroup (1024 threads), order-preserving compaction of image-0 candidates
@@ -178,6 +186,16 @@ __global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long
     if (tid == 0) num_out[0] = (int64_t)base_cnt;
 }
 
+// rows of dets[n,5] selected by keep[k] -> boxes[k,4], scores[k]  (posenet.py:283-285 gathers)
+__global__ void gather_dets_kernel(const float* __restrict__ dets, const int64_t* __restrict__ keep, int k,
+                                   float* __restrict__ boxes, float* __restrict__ scores) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const float* s = dets + keep[i] * 5;
+    boxes[i * 4 + 0] = s[0]; boxes[i * 4 + 1] = s[1]; boxes[i * 4 + 2] = s[2]; boxes[i * 4 + 3] = s[3];
+    scores[i] = s[4];
+}
+
 inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
 
 }  // namespace
@@ -191,10 +209,22 @@ extern "C" int mpn_box_decode_clip(const float* anchors, const float* deltas, fl
     return mpn_launch_status();
 }
 
+extern "C" int mpn_clip_boxes(float* boxes, int64_t n, float img_w, float img_h, void* stream) {
+    MPN_CHECK_ARG(boxes && n > 0);
+    hipLaunchKernelGGL(clip_boxes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boxes, (long)n, img_w, img_h);
+    return mpn_launch_status();
+}
+
 extern "C" int mpn_score_filter(const float* boxes, const float* scores, int A, float thresh, float* dets, int32_t* src_idx,
                                 int32_t* count, void* stream) {
     MPN_CHECK_ARG(boxes && scores && dets && src_idx && count && A > 0);
     hipLaunchKernelGGL(score_filter_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, boxes, scores, A, thresh, dets, src_idx, count);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_gather_dets(const float* dets, const int64_t* keep, int k, float* boxes, float* scores, void* stream) {
+    MPN_CHECK_ARG(dets && keep && boxes && scores && k > 0);
+    hipLaunchKernelGGL(gather_dets_kernel, dim3((k + 255) / 256), dim3(256), 0, (hipStream_t)stream, dets, keep, k, boxes, scores);
     return mpn_launch_status();
 }
 

@@ -1,0 +1,426 @@
+"""Forward/backward runtime of the hot path.
+
+The reference lets torch autograd drive ~400 separate ATen ops per step (network/fpn.py,
+network/posenet.py) and accumulates gradients with extra elementwise kernels.  Here the whole
+poseNet forward is recorded on an explicit tape of fused HIP launches (``ops``); ``loss.backward()``
+enters through ONE autograd node (``_NetFn``) and the tape is replayed in reverse with
+caller-controlled gradient buffers: every kernel either overwrites or accumulates (dgrad /
+bn_bwd / upsample_bwd take an ``accumulate`` flag), so no torch compute kernel runs in either pass.
+Weight gradients are accumulated straight into the flat gradient arena; when a data-parallel reducer
+is attached it is told as each parameter's gradient completes, so RCCL all-reduces of finished
+arena slices overlap the rest of backward.
+"""
+import ctypes
+
+import torch
+
+from . import ops
+from ._lib import call
+from .ops import Act, round_up
+
+
+class Ctx(object):
+    """State of one forward pass (tape + gradient buffers)."""
+
+    def __init__(self, train):
+        self.train = train
+        self.tape = []
+        self.grads = {}          # id(Act) -> Act
+        self.keep = []           # keeps Acts alive while their id() is used as a key
+        self.out_grads = {}      # export slot -> torch grad tensor (filled by _NetFn.backward)
+        self.wt = {}             # id(weight param) -> transposed operand
+        self.uses = {}           # id(param) -> number of pending gradient contributions
+        self.bn_train_ran = False
+
+    def gbuf(self, act, dtype=None):
+        """Gradient buffer for ``act``: returns (Act, existed)."""
+        g = self.grads.get(id(act))
+        if g is not None:
+            return g, True
+        g = Act(torch.empty(act.t.shape, dtype=dtype or act.t.dtype, device=act.t.device), act.C)
+        self.grads[id(act)] = g
+        self.keep.append(act)
+        return g, False
+
+    def grad_of(self, act):
+        return self.grads.get(id(act))
+
+    def set_grad(self, act, g):
+        self.grads[id(act)] = g
+        self.keep.append(act)
+
+    def pop_grad(self, act):
+        return self.grads.pop(id(act), None)
+
+
+class Engine(object):
+    def __init__(self, model):
+        self.m = model
+
+    # ------------------------------------------------------------------ weights
+    @property
+    def cdt(self):
+        return self.m.compute_dtype
+
+    def w_fwd(self, layer):
+        """Forward operand [Cout][R][S][Cin] in the compute dtype (a view, never a copy in f32)."""
+        ar = self.m._arena
+        if self.cdt == torch.float32:
+            return ar.data_seg(layer.weight)
+        return ar.data_seg(layer.weight, ar.bf16)
+
+    def w_t(self, ctx, layer):
+        """dgrad operand Wt[Cin][R][S][Cout_pad], refreshed once per forward."""
+        key = id(layer.weight)
+        wt = ctx.wt.get(key)
+        if wt is None:
+            O, I, R, S = layer.weight.shape
+            kc = 32 if self.cdt == torch.bfloat16 else 16
+            opad = round_up(O, kc)
+            wt = torch.empty((I, R, S, opad), dtype=self.cdt, device=layer.weight.device)
+            ops.weight_transpose(self.m._arena.data_seg(layer.weight), wt, O, R * S, I, opad)
+            ctx.wt[key] = wt
+        return wt
+
+    def _note_use(self, ctx, p):
+        if p is not None and p.requires_grad:
+            ctx.uses[id(p)] = ctx.uses.get(id(p), 0) + 1
+
+    def _grad_done(self, ctx, p):
+        n = ctx.uses.get(id(p), 0) - 1
+        ctx.uses[id(p)] = n
+        if n == 0 and self.m._reducer is not None:
+            self.m._reducer.param_ready(p)
+
+    # ------------------------------------------------------------------ ops
+    def conv(self, ctx, x, layer, act=0, res=None, res_mode=0, stats=False, out_f32=False, tag=""):
+        O, I, R, S = layer.weight.shape
+        stride, pad = layer.stride[0], layer.padding[0]
+        bias = layer.bias
+        y, st = ops.conv_forward(x, self.w_fwd(layer), O, R, S, stride, pad, bias=bias.data if bias is not None else None,
+                                 act=act, res=res, res_mode=res_mode, want_stats=stats, out_f32=out_f32, tag=tag)
+        if ctx.train:
+            y.needs_grad = bool(x.needs_grad or layer.weight.requires_grad or (bias is not None and bias.requires_grad)
+                                or (res is not None and res.needs_grad))
+            if y.needs_grad:
+                self._note_use(ctx, layer.weight)
+                self._note_use(ctx, bias)
+                if x.needs_grad:
+                    self.w_t(ctx, layer)       # make the transposed operand now (weights may change before backward)
+                ctx.tape.append(lambda: self._conv_bwd(ctx, x, layer, y, act, res, res_mode))
+        return y, st
+
+    def _conv_bwd(self, ctx, x, layer, y, act, res, res_mode):
+        dy = ctx.pop_grad(y)
+        O, I, R, S = layer.weight.shape
+        stride, pad = layer.stride[0], layer.padding[0]
+        bias = layer.bias
+        if dy is None:       # nothing flowed back through this output (e.g. unused head)
+            if layer.weight.requires_grad:
+                self._grad_done(ctx, layer.weight)
+            if bias is not None and bias.requires_grad:
+                self._grad_done(ctx, bias)
+            return
+        if dy.t.dtype != self.cdt:
+            raise ops._lib.MpnError("gradient dtype mismatch for %s" % y.tag)
+        if act == 1:
+            dy = ops.relu_backward(dy, y)
+        elif act == 2:
+            raise ops._lib.MpnError("sigmoid backward is handled at the detection edge")
+        if res is not None and res.needs_grad:
+            g, existed = ctx.gbuf(res)
+            if res_mode == 2:
+                ops.upsample_backward(dy, g, existed)
+            elif existed:
+                ops.add_inplace(g, dy)
+            else:
+                g.t.copy_(dy.t)
+        ar = self.m._arena
+        if layer.weight.requires_grad:
+            ops.conv_wgrad(x, dy, ar.grad_seg(layer.weight), O, R, S, stride, pad)
+            self._grad_done(ctx, layer.weight)
+        if bias is not None and bias.requires_grad:
+            ops.bias_grad(dy, ar.grad_seg(bias), O)
+            self._grad_done(ctx, bias)
+        if x.needs_grad:
+            g, existed = ctx.gbuf(x)
+            wt = self.w_t(ctx, layer)
+            ops.conv_forward(dy, wt, I, R, S, stride, pad, mode=1, out_hw=(x.H, x.W), cin=wt.shape[3], out=g, accumulate=existed)
+
+    def bn(self, ctx, y, stats, layer, relu, res=None, tag=""):
+        train_stats = layer.training
+        if train_stats:
+            st = ops.bn_finalize_train(stats, y.P, layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var,
+                                       layer.momentum if layer.momentum is not None else 0.1, layer.eps)
+            ctx.bn_train_ran = True
+        else:
+            st = ops.bn_finalize_eval(layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var, layer.eps)
+        z = ops.bn_act(y, st, relu, res=res, tag=tag)
+        if ctx.train:
+            z.needs_grad = bool(y.needs_grad or layer.weight.requires_grad or layer.bias.requires_grad
+                                or (res is not None and res.needs_grad))
+            if z.needs_grad:
+                self._note_use(ctx, layer.weight)
+                self._note_use(ctx, layer.bias)
+                ctx.tape.append(lambda: self._bn_bwd(ctx, y, z, st, layer, relu, res, train_stats))
+        return z
+
+    def _bn_bwd(self, ctx, y, z, st, layer, relu, res, train_stats):
+        dz = ctx.pop_grad(z)
+        wg, bg = layer.weight.requires_grad, layer.bias.requires_grad
+        if dz is None:
+            if wg:
+                self._grad_done(ctx, layer.weight)
+            if bg:
+                self._grad_done(ctx, layer.bias)
+            return
+        ar = self.m._arena
+        dres, dres_acc = None, False
+        if res is not None and res.needs_grad:
+            dres, dres_acc = ctx.gbuf(res)
+        want_dy = y.needs_grad
+        dy = ops.bn_backward(dz, z, y, st, layer.weight.data, relu, train_stats,
+                             dgamma=ar.grad_seg(layer.weight) if wg else None,
+                             dbeta=ar.grad_seg(layer.bias) if bg else None,
+                             want_dy=want_dy, dres=dres, dres_acc=dres_acc)
+        if wg:
+            self._grad_done(ctx, layer.weight)
+        if bg:
+            self._grad_done(ctx, layer.bias)
+        if want_dy:
+            ctx.set_grad(y, dy)
+
+    def relu(self, ctx, x):
+        z = ops.relu_forward(x)
+        if ctx.train and x.needs_grad:
+            z.needs_grad = True
+
+            def bwd():
+                dz = ctx.pop_grad(z)
+                if dz is None:
+                    return
+                g, existed = ctx.gbuf(x)
+                ops.relu_backward(dz, z, g, existed)
+            ctx.tape.append(bwd)
+        return z
+
+    def maxpool(self, ctx, x):
+        need = ctx.train and x.needs_grad
+        y, idx = ops.maxpool_forward(x, needs_grad=need)
+        if need:
+            def bwd():
+                dy = ctx.pop_grad(y)
+                if dy is None:
+                    return
+                ctx.set_grad(x, ops.maxpool_backward(dy, idx, x))
+            ctx.tape.append(bwd)
+        return y
+
+    def concat_up(self, ctx, srcs, Ho, Wo):
+        """torch.cat((up8(p5), up4(p4), up2(p3), p2), 1)  — posenet.py:311-315 — as channel-slice writes."""
+        B = srcs[0].B
+        Ctot = sum(s.C for s in srcs)
+        dst = Act(torch.empty((B, Ho, Wo, Ctot), dtype=srcs[0].t.dtype, device=srcs[0].t.device), Ctot)
+        off = 0
+        offs = []
+        for s in srcs:
+            ops.upsample_slice(s, dst, off)
+            offs.append(off)
+            off += s.C
+        if ctx.train and any(s.needs_grad for s in srcs):
+            dst.needs_grad = True
+
+            def bwd():
+                d = ctx.pop_grad(dst)
+                if d is None:
+                    return
+                for s, o in zip(srcs, offs):
+                    if s.needs_grad:
+                        g = Act(torch.empty_like(s.t), s.C)
+                        ops.upsample_slice_backward(d, g, o)
+                        ctx.set_grad(s, g)
+            ctx.tape.append(bwd)
+        return dst
+
+    def export(self, ctx, src, C, Ho, Wo, slot):
+        """Internal padded tensor -> exact f32 API tensor (nearest up-sampled to Ho x Wo)."""
+        out = ops.export_f32(src, C, Ho, Wo)
+        if ctx.train and src.needs_grad:
+            def bwd():
+                g = ctx.out_grads.get(slot)
+                if g is None:
+                    return
+                ctx.set_grad(src, ops.import_grad(g, src, self.cdt))
+            ctx.tape.append(bwd)
+        return out
+
+    # ------------------------------------------------------------------ network pieces
+    def stem(self, ctx, img):
+        """conv1 7x7/s2 + bn1 + relu + maxpool (fpn.py:99-100) via the NHWC4 packed row-conv."""
+        f = self.m.fpn
+        B, _, H, W = img.shape
+        Hp, Wp = H + 6, W + 8
+        img = img.detach()
+        if img.dtype != torch.float32:
+            img = img.float()
+        packed = torch.empty((B, Hp, Wp, 4), dtype=self.cdt, device=img.device)
+        call("mpn_stem_pack_image", ops.ptr(img), img.stride(0), img.stride(1), img.stride(2), img.stride(3), ops.ptr(packed),
+             B, H, W, ops.dtype_code(self.cdt), ops.stream_ptr())
+        xa = Act(packed, 4)
+        w = f.conv1.weight
+        wp = torch.empty((64, 7, 32), dtype=self.cdt, device=img.device)
+        call("mpn_stem_pack_weight", ops.ptr(self.m._arena.data_seg(w)), ops.ptr(wp), 64, ops.dtype_code(self.cdt), ops.stream_ptr())
+        Ho, Wo = ops.conv_out_hw(H, W, 7, 7, 2, 3)
+        geom = (Hp, Wp, Hp * Wp * 4, Wp * 4, 4)
+        bn_train = f.bn1.training
+        y, st = ops.conv_forward(xa, wp, 64, 7, 1, 2, 0, cin=32, x_geom=geom, out_hw=(Ho, Wo), want_stats=bn_train)
+        if ctx.train and w.requires_grad:
+            y.needs_grad = True
+            self._note_use(ctx, w)
+
+            def bwd():
+                dy = ctx.pop_grad(y)
+                if dy is not None:
+                    dwp = torch.zeros((64, 7, 32), dtype=torch.float32, device=img.device)
+                    ops.conv_wgrad(xa, dy, dwp, 64, 7, 1, 2, 0, cin=32, x_geom=geom)
+                    call("mpn_stem_unpack_wgrad", ops.ptr(dwp), ops.ptr(self.m._arena.grad_seg(w)), 64, ops.stream_ptr())
+                self._grad_done(ctx, w)
+            ctx.tape.append(bwd)
+        z = self.bn(ctx, y, st, f.bn1, True)
+        return self.maxpool(ctx, z)
+
+    def bottleneck(self, ctx, x, blk):
+        """fpn.py:28-34."""
+        y1, s1 = self.conv(ctx, x, blk.conv1, stats=blk.bn1.training)
+        z1 = self.bn(ctx, y1, s1, blk.bn1, True)
+        y2, s2 = self.conv(ctx, z1, blk.conv2, stats=blk.bn2.training)
+        z2 = self.bn(ctx, y2, s2, blk.bn2, True)
+        y3, s3 = self.conv(ctx, z2, blk.conv3, stats=blk.bn3.training)
+        if len(blk.downsample) > 0:
+            ys, ss = self.conv(ctx, x, blk.downsample[0], stats=blk.downsample[1].training)
+            sc = self.bn(ctx, ys, ss, blk.downsample[1], False)
+        else:
+            sc = x
+        return self.bn(ctx, y3, s3, blk.bn3, True, res=sc)
+
+    def backbone(self, ctx, img):
+        f = self.m.fpn
+        c = self.stem(ctx, img)
+        feats = []
+        for layer in (f.layer1, f.layer2, f.layer3, f.layer4):
+            for blk in layer:
+                c = self.bottleneck(ctx, c, blk)
+            feats.append(c)
+        return feats      # c2..c5
+
+    def det_pyramid(self, ctx, c3, c4, c5):
+        """fpn.py:107-114 (p4 is built from the UN-smoothed p5)."""
+        f = self.m.fpn
+        p6, _ = self.conv(ctx, c5, f.conv6)
+        p7, _ = self.conv(ctx, self.relu(ctx, p6), f.conv7)
+        p5, _ = self.conv(ctx, c5, f.latlayer1)
+        p4, _ = self.conv(ctx, c4, f.latlayer2, res=p5, res_mode=2)
+        p3, _ = self.conv(ctx, c3, f.latlayer3, res=p4, res_mode=2)
+        p5s, _ = self.conv(ctx, p5, f.toplayer0)
+        p4s, _ = self.conv(ctx, p4, f.toplayer1)
+        p3s, _ = self.conv(ctx, p3, f.toplayer2)
+        return [p3s, p4s, p5s, p6, p7]
+
+    def kp_pyramid(self, ctx, c2, c3, c4, c5):
+        """fpn.py:117-124 (fp5 is not smoothed)."""
+        f = self.m.fpn
+        fp5, _ = self.conv(ctx, c5, f.toplayer)
+        fp4, _ = self.conv(ctx, c4, f.flatlayer1, res=fp5, res_mode=2)
+        fp3, _ = self.conv(ctx, c3, f.flatlayer2, res=fp4, res_mode=2)
+        fp2, _ = self.conv(ctx, c2, f.flatlayer3, res=fp3, res_mode=2)
+        fp4s, _ = self.conv(ctx, fp4, f.smooth1)
+        fp3s, _ = self.conv(ctx, fp3, f.smooth2)
+        fp2s, _ = self.conv(ctx, fp2, f.smooth3)
+        return [fp2s, fp3s, fp4s, fp5]
+
+    def keypoint_head(self, ctx, feats, intermediate):
+        """posenet.py:288-318 / :243-257.  Returns (pred, [k2,k3,k4,k5]) as f32 API tensors."""
+        m = self.m
+        p2, p3, p4, p5 = feats
+        Ho, Wo = p2.H, p2.W
+        saved = []
+        if intermediate:
+            for i, (src, layer) in enumerate(((p2, m.convfin_k2), (p3, m.convfin_k3), (p4, m.convfin_k4), (p5, m.convfin_k5))):
+                k, _ = self.conv(ctx, src, layer, out_f32=True)
+                saved.append(self.export(ctx, k, 19, Ho, Wo, "k%d" % i))
+        q5, _ = self.conv(ctx, self.conv(ctx, p5, m.convt1)[0], m.convs1)
+        q4, _ = self.conv(ctx, self.conv(ctx, p4, m.convt2)[0], m.convs2)
+        q3, _ = self.conv(ctx, self.conv(ctx, p3, m.convt3)[0], m.convs3)
+        q2, _ = self.conv(ctx, self.conv(ctx, p2, m.convt4)[0], m.convs4)
+        cat = self.concat_up(ctx, [q5, q4, q3, q2], Ho, Wo)
+        h, _ = self.conv(ctx, cat, m.conv2, act=1)
+        pr, _ = self.conv(ctx, h, m.convfin, out_f32=True)
+        pred = self.export(ctx, pr, 18, Ho, Wo, "pred")
+        return pred, saved
+
+    def detection_head(self, ctx, feats):
+        """posenet.py:327-328: shared towers over p3..p7, outputs written straight into [B,A,4] / [B,A,1]."""
+        m = self.m
+        B = feats[0].B
+        dev = feats[0].t.device
+        cells = [f.H * f.W for f in feats]
+        A = 9 * sum(cells)
+        reg_all = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
+        cls_all = torch.empty((B, A, 1), dtype=torch.float32, device=dev)
+        outs = []
+        off = 0
+        for f, n in zip(feats, cells):
+            r = f
+            for layer in (m.regressionModel.conv1, m.regressionModel.conv2, m.regressionModel.conv3, m.regressionModel.conv4):
+                r, _ = self.conv(ctx, r, layer, act=1)
+            ro, _ = self.conv(ctx, r, m.regressionModel.output, out_f32=True)
+            c = f
+            for layer in (m.classificationModel.conv1, m.classificationModel.conv2, m.classificationModel.conv3, m.classificationModel.conv4):
+                c, _ = self.conv(ctx, c, layer, act=1)
+            co, _ = self.conv(ctx, c, m.classificationModel.output, out_f32=True)
+            outs.append((ro, co, off, n))
+            off += n * 9
+        # pack the per-level outputs, then one sigmoid over [B,A,1] (its backward needs only p)
+        for ro, co, o, n in outs:
+            call("mpn_det_pack", ops.ptr(ro.t), 0, ctypes.c_void_p(reg_all.data_ptr() + o * 4 * 4), B, n, ro.Cs, 36, A * 4, ops.stream_ptr())
+            call("mpn_det_pack", ops.ptr(co.t), 0, ctypes.c_void_p(cls_all.data_ptr() + o * 4), B, n, co.Cs, 9, A, ops.stream_ptr())
+        call("mpn_sigmoid_forward", ops.ptr(cls_all), ops.ptr(cls_all), cls_all.numel(), ops.stream_ptr())
+        if ctx.train:
+            if any(x[0].needs_grad or x[1].needs_grad for x in outs):
+                def bwd():
+                    gr, gc = ctx.out_grads.get("reg"), ctx.out_grads.get("cls")
+                    if gc is not None:
+                        gc = gc.contiguous()
+                        dlogit = torch.empty_like(cls_all)
+                        call("mpn_sigmoid_backward", ops.ptr(gc), ops.ptr(cls_all), ops.ptr(dlogit), cls_all.numel(), ops.stream_ptr())
+                    if gr is not None:
+                        gr = gr.contiguous()
+                    for ro, co, o, n in outs:
+                        if gr is not None and ro.needs_grad:
+                            d = Act(torch.empty(ro.t.shape, dtype=self.cdt, device=dev), 36)
+                            call("mpn_det_unpack", ctypes.c_void_p(gr.data_ptr() + o * 4 * 4), ops.ptr(d.t), ops.dtype_code(self.cdt),
+                                 B, n, d.Cs, 36, A * 4, ops.stream_ptr())
+                            ctx.set_grad(ro, d)
+                        if gc is not None and co.needs_grad:
+                            d = Act(torch.empty(co.t.shape, dtype=self.cdt, device=dev), 9)
+                            call("mpn_det_unpack", ctypes.c_void_p(dlogit.data_ptr() + o * 4), ops.ptr(d.t), ops.dtype_code(self.cdt),
+                                 B, n, d.Cs, 9, A, ops.stream_ptr())
+                            ctx.set_grad(co, d)
+                ctx.tape.append(bwd)
+        return cls_all, reg_all
+
+    # ------------------------------------------------------------------ backward
+    def run_backward(self, ctx, out_grads):
+        m = self.m
+        ctx.out_grads = out_grads
+        m._arena.ensure_grads()
+        if m._reducer is not None:
+            m._reducer.begin()
+        tape = ctx.tape
+        while tape:
+            tape.pop()()
+        ctx.grads.clear()
+        ctx.keep = []
+        ctx.wt.clear()
+        if m._reducer is not None:
+            m._reducer.finish()

@@ -62,6 +62,45 @@ class Act(object):
         return self.t[..., : self.C].permute(0, 3, 1, 2)
 
 
+class _KernelEvents(object):
+    """Optional live timing of conv launches with HIP events on the launch stream (bench.py roofline).
+
+    Each instrumented launch is bracketed by two events recorded on the SAME stream the kernel is
+    enqueued on (torch's current stream); durations are read after the timed region."""
+
+    def __init__(self):
+        self.on = False
+        self.rec = []
+
+    def enable(self):
+        self.on = True
+        self.rec = []
+
+    def disable(self):
+        self.on = False
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, name, flops, e0):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.rec.append((name, flops, e0, e1))
+
+    def summary(self):
+        out = {}
+        for name, flops, e0, e1 in self.rec:
+            d = out.setdefault(name, {"ms": 0.0, "flops": 0.0, "n": 0})
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["n"] += 1
+        return out
+
+
+KERNEL_EVENTS = _KernelEvents()
+
 _ws = {}
 
 
@@ -136,7 +175,17 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         tiles = call("mpn_conv_stats_tiles", ctypes.byref(p))
         stats = torch.empty((tiles, Cout, 2), dtype=torch.float32, device=dev)
         p.stats = stats.data_ptr()
-    call("mpn_conv_forward", ctypes.byref(p), stream_ptr())
+    if KERNEL_EVENTS.on:
+        e0 = KERNEL_EVENTS.begin()
+        call("mpn_conv_forward", ctypes.byref(p), stream_ptr())
+        cs = p.Cout_store
+        tc = 128 if cs > 64 else (64 if cs > 32 else 32)
+        # algorithmic FLOPs: 2 * output pixels * Cout * taps * Cin; a stride-s dgrad only has 1/s^2 live taps
+        live = (R * S) / float(stride * stride) if mode == 1 else R * S
+        flops = 2.0 * x.B * Ho * Wo * Cout * live * min(Cin, x.C if x_geom is None else Cin)
+        KERNEL_EVENTS.end("conv_igemm_kernel<%s,%d,128>" % ("bf16" if dt == torch.bfloat16 else "f32", tc), flops, e0)
+    else:
+        call("mpn_conv_forward", ctypes.byref(p), stream_ptr())
     return out, stats
 
 
@@ -165,7 +214,13 @@ def conv_wgrad(x, dy, dw, Cout, R, S, stride, pad, cin=None, x_geom=None):
     if chunks > 1:
         ws = workspace(chunks * Cout * R * S * Cin * 4, dev, slot=1)
         p.ws = ws.data_ptr()
-    call("mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
+    if KERNEL_EVENTS.on:
+        e0 = KERNEL_EVENTS.begin()
+        call("mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
+        KERNEL_EVENTS.end("conv_wgrad(+reduce)<%s>" % ("bf16" if dt == torch.bfloat16 else "f32"),
+                          2.0 * x.B * dy.H * dy.W * Cout * R * S * Cin, e0)
+    else:
+        call("mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
 
 
 def bias_grad(dy, db, C):
@@ -331,11 +386,28 @@ def nms(dets, thresh, mode=0):
     return keep[:k]
 
 
-def box_decode_clip(anchors, deltas, img_w, img_h):
+def box_decode_clip(anchors, deltas, img_w, img_h, clip=True):
     B, A, _ = deltas.shape
     boxes = torch.empty((B, A, 4), dtype=torch.float32, device=deltas.device)
-    call("mpn_box_decode_clip", ptr(anchors), ptr(deltas), ptr(boxes), B, A, float(img_w), float(img_h), stream_ptr())
+    call("mpn_box_decode_clip", ptr(anchors), ptr(deltas), ptr(boxes), B, A, float(img_w) if clip else -1.0,
+         float(img_h) if clip else -1.0, stream_ptr())
     return boxes
+
+
+def clip_boxes_(boxes, img_w, img_h):
+    if not boxes.is_contiguous():
+        raise _lib.MpnError("clip_boxes_ needs a contiguous [B,A,4] tensor")
+    call("mpn_clip_boxes", ptr(boxes), boxes.numel() // 4, float(img_w), float(img_h), stream_ptr())
+    return boxes
+
+
+def gather_dets(dets, keep):
+    k = keep.numel()
+    boxes = torch.empty((k, 4), dtype=torch.float32, device=dets.device)
+    scores = torch.empty((k,), dtype=torch.float32, device=dets.device)
+    if k > 0:
+        call("mpn_gather_dets", ptr(dets), ptr(keep), k, ptr(boxes), ptr(scores), stream_ptr())
+    return boxes, scores
 
 
 def score_filter(boxes0, scores0, thresh):

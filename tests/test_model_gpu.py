@@ -1,0 +1,259 @@
+"""Whole-path parity on the MI355X: poseNet forward / losses / gradients / optimizer steps vs golden
+vectors produced by the REAL reference (tests/golden/make_golden.py) and vs the CPU oracle.
+
+Tolerance (BASELINE.json north_star): heat-maps within 1e-3 abs in fp32 on identical inputs (plus
+rel-L2 <= 1e-4); NMS box indices bit-exact.  Gradients: per-parameter L2 norms within 2e-3 relative.
+bf16 runs are judged against fp32 with dtype-appropriate bounds (rel-L2 <= 3e-2).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import gold, report
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "GPU tests selected but no GPU is visible"
+    from multiposenet.pytorch_amd import _lib
+    _lib.lib()
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+_models = {}
+
+
+def get_model(layers, dtype):
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    key = (layers, dtype)
+    if key not in _models:
+        _models.clear()
+        torch.cuda.empty_cache()
+        m = poseNet(layers, compute_dtype=dtype).cuda()
+        _models[key] = m
+    m = _models[key]
+    load_he(m)
+    for p in m.parameters():
+        p.requires_grad = True
+    return m
+
+
+def load_he(model, seed=0):
+    from oracle import weightgen
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = weightgen.gen_state_dict(shapes, seed=seed, flavour="he", skip_prefixes=("prn.",))
+    missing = model.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    assert all(k.startswith("prn.") for k in missing.missing_keys)
+    return sd
+
+
+def close(name, got, ref, atol, rel_l2):
+    got = got.detach().float().cpu().double()
+    ref = ref.double()
+    err = (got - ref).abs().max().item()
+    rl2 = ((got - ref).norm() / max(ref.norm().item(), 1e-12)).item()
+    report("%-58s abs=%.3e (lim %.1e)  relL2=%.3e (lim %.1e) refmax=%.3g" % (name, err, atol, rl2, rel_l2, ref.abs().max().item()))
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert err <= atol, "%s: abs err %.3e > %.1e" % (name, err, atol)
+    assert rl2 <= rel_l2, "%s: rel-L2 %.3e > %.1e" % (name, rl2, rel_l2)
+
+
+@pytest.mark.parametrize("layers", [50, 101])
+def test_forward_matches_reference_golden_fp32(layers):
+    from oracle import weightgen
+    g = gold("g2_forward_r%d.npz" % layers)
+    model = get_model(layers, torch.float32)
+    cases = [("eval", 2, 64, 64), ("eval", 2, 128, 128), ("train", 2, 128, 128)]
+    if layers == 50:
+        cases.insert(1, ("eval", 1, 128, 96))
+    for mode, b, h, w in cases:
+        tag = "%s_%dx%dx%d" % (mode, b, h, w)
+        img = t(weightgen.gen_images(1, b, h, w)).cuda()
+        load_he(model)
+        model.train() if mode == "train" else model.eval()
+        with torch.no_grad():
+            pred, saved = model([img, "keypoint_subnet"])
+            assert pred.shape == (b, 18, h // 4, w // 4) and len(saved) == 5 and saved[4] is pred
+            close("R%d kp pred %s" % (layers, tag), pred, t(g["kp_pred_" + tag]), 1e-3, 1e-4)
+            for j in range(4):
+                assert saved[j].shape == (b, 19, h // 4, w // 4)
+                close("R%d kp saved%d %s" % (layers, j, tag), saved[j], t(g["kp_saved%d_%s" % (j, tag)]), 1e-3, 1e-4)
+            if mode == "train":
+                close("bn1 running_mean " + tag, model.fpn.bn1.running_mean, t(g["bn1_rm_" + tag]), 1e-5, 1e-5)
+                close("bn1 running_var " + tag, model.fpn.bn1.running_var, t(g["bn1_rv_" + tag]), 1e-5, 1e-5)
+                close("layer4.2.bn3 running_var " + tag, model.fpn.layer4[2].bn3.running_var, t(g["l4bn3_rv_" + tag]), 1e-5, 1e-4)
+                assert int(model.fpn.bn1.num_batches_tracked.item()) == 1
+                load_he(model)
+                model.train()
+            empty, dsaved = model([img, "detection_subnet"])
+            assert empty == [] and len(dsaved) == 3
+            close("R%d det cls %s" % (layers, tag), dsaved[0], t(g["det_cls_" + tag]), 1e-3, 1e-4)
+            close("R%d det reg %s" % (layers, tag), dsaved[1], t(g["det_reg_" + tag]), 1e-3, 1e-4)
+            if mode == "eval":
+                heat, det = model([img, "both"])
+                close("R%d both heat %s" % (layers, tag), heat, t(g["both_heat_" + tag]), 1e-3, 1e-4)
+                ref_scores = g["both_scores_" + tag]
+                assert det[0].shape[0] == ref_scores.shape[0], "number of kept boxes differs: %d vs %d" % (det[0].shape[0], ref_scores.shape[0])
+                close("R%d both scores %s" % (layers, tag), det[0], t(ref_scores), 1e-4, 1e-4)
+                close("R%d both boxes %s" % (layers, tag), det[2], t(g["both_boxes_" + tag]), 2e-3, 1e-4)
+                assert det[1].dtype == torch.int64 and int(det[1].abs().sum().item()) == 0
+
+
+def _grad_check(model, g, tag, rel=2e-3):
+    names = list(g["gnames_" + tag])
+    ref = dict(zip(names, g["gnorms_" + tag]))
+    pd = dict(model.named_parameters())
+    worst = 0.0
+    scale = max(ref.values())
+    for n in names:
+        gr = pd[n].grad
+        assert gr is not None, "missing grad for " + n
+        got = gr.double().norm().item()
+        e = abs(got - ref[n]) / max(ref[n], 1e-6 * scale)
+        if e > worst:
+            worst = e
+            worst_n = n
+        assert e <= rel or abs(got - ref[n]) <= 1e-6 * scale, "grad norm %s: got %.6e ref %.6e (rel %.2e)" % (n, got, ref[n], e)
+    report("grad norms %-8s %d params, worst rel err %.3e (%s)" % (tag, len(names), worst, worst_n))
+    for k in g.files:
+        if k.startswith("g_") and k.endswith("_" + tag):
+            n = k[2:-len(tag) - 1]
+            stride = int(g["gstride_%s_%s" % (n, tag)][0])
+            got = pd[n].grad.detach().cpu().reshape(-1)[::stride]
+            r = t(g[k])
+            close("grad sample %s %s" % (n, tag), got, r, 2e-3 * max(r.abs().max().item(), 1e-8), 2e-3)
+
+
+def test_losses_and_gradients_match_reference_golden_fp32():
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    from oracle import weightgen
+    g = gold("g3_losses_r50.npz")
+    b, s = 2, 128
+    img = t(weightgen.gen_images(2, b, s, s)).cuda()
+    heat, wgt = weightgen.gen_keypoint_gt(2, b, s // 4, s // 4)
+    anno = t(g["anno"]).cuda()
+    model = get_model(50, torch.float32)
+    # --- keypoint subnet, train-mode BN (trainer.py:172)
+    model.train()
+    pred, saved = model([img, "keypoint_subnet"])
+    loss, log = poseNet.build_loss(saved, "keypoint_subnet", t(heat).cuda(), t(wgt).cuda())
+    model.zero_grad()
+    loss.backward()
+    ref = g["kp_loss"]
+    assert abs(loss.item() - ref[0]) <= 2e-4 * abs(ref[0]), (loss.item(), ref[0])
+    for k, r in zip(g["kp_lognames"], ref[1:]):
+        assert abs(log[str(k)] - r) <= 2e-4 * max(abs(r), 1.0), (k, log[str(k)], r)
+    assert list(log.keys()) == [str(k) for k in g["kp_lognames"]]
+    _grad_check(model, g, "kp")
+    # --- detection subnet, frozen BN (trainer.py:173-174)
+    load_he(model)
+    model.train()
+    model.freeze_bn()
+    model.zero_grad()
+    _, dsaved = model([img, "detection_subnet"])
+    dloss, dlog = poseNet.build_loss(dsaved, "detection_subnet", anno)
+    dloss.backward()
+    ref = g["det_loss"]
+    for got, r in zip((dlog["total_loss"], dlog["classification_loss"], dlog["regression_loss"]), ref):
+        assert abs(got - r) <= 2e-4 * max(abs(r), 1.0), (got, r)
+    _grad_check(model, g, "det")
+    # --- combined step: one backbone pass, kp + det losses
+    load_he(model)
+    model.train()
+    model.zero_grad()
+    pred, (ksaved, dsaved) = model([img, "train_both"])
+    tl, tlog = poseNet.build_loss((ksaved, dsaved), "train_both", t(heat).cuda(), t(wgt).cuda(), anno)
+    tl.backward()
+    ref = g["both_loss"]
+    assert abs(tl.item() - (ref[0] + ref[1])) <= 2e-4 * abs(ref[0] + ref[1])
+    _grad_check(model, g, "both")
+
+
+def test_three_adam_steps_match_reference_golden_fp32():
+    """cfg-1 shapes (R50 keypoint 256^2 B2): loss trajectory + updated params after 3 Adam steps."""
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    from multiposenet.pytorch_amd.optim import FusedAdam
+    from oracle import weightgen
+    g = gold("g8_steps_r50.npz")
+    img = t(weightgen.gen_images(8, 2, 256, 256)).cuda()
+    heat, wgt = weightgen.gen_keypoint_gt(8, 2, 64, 64)
+    heat, wgt = t(heat).cuda(), t(wgt).cuda()
+    for which in ("torch", "fused"):
+        model = get_model(50, torch.float32)
+        model.train()
+        for name, module in model.fpn.named_children():
+            if name in ("conv6", "conv7", "latlayer1", "latlayer2", "latlayer3", "toplayer0", "toplayer1", "toplayer2"):
+                for p in module.parameters():
+                    p.requires_grad = False
+        for name, module in model.named_children():
+            if name in ("regressionModel", "classificationModel", "prn"):
+                for p in module.parameters():
+                    p.requires_grad = False
+        if which == "torch":
+            opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.0)
+        else:
+            opt = FusedAdam(model, lr=1e-4, weight_decay=0.0)
+        losses = []
+        for step in range(3):
+            pred, saved = model([img, "keypoint_subnet"])
+            loss, log = poseNet.build_loss(saved, "keypoint_subnet", heat, wgt)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        ref = g["losses"][:, 0]
+        report("adam(%s) losses %s  ref %s" % (which, losses, list(ref)))
+        for a, r in zip(losses, ref):
+            assert abs(a - r) <= 2e-3 * abs(r), (which, losses, list(ref))
+        assert model.fpn.conv6.weight.grad is None or float(model.fpn.conv6.weight.grad.abs().sum()) == 0.0
+        # Adam moves every element by ~lr per step whatever the gradient magnitude, so an element whose
+        # gradient is ~0 may differ by up to 2*steps*lr = 6e-4; the rel-L2 bound is the meaningful one.
+        close("convfin.bias after 3 steps (%s)" % which, model.convfin.bias, t(g["convfin_bias"]), 6.5e-4, 2e-2)
+        close("bn1.weight after 3 steps (%s)" % which, model.fpn.bn1.weight, t(g["bn1_weight"]), 6.5e-4, 1e-3)
+        close("bn1.running_mean after 3 steps (%s)" % which, model.fpn.bn1.running_mean, t(g["bn1_rm"]), 1e-4, 1e-3)
+        assert int(model.fpn.bn1.num_batches_tracked.item()) == int(g["nbt"][0])
+
+
+def test_bf16_tracks_fp32():
+    from oracle import weightgen
+    img = t(weightgen.gen_images(1, 2, 128, 128)).cuda()
+    g = gold("g2_forward_r50.npz")
+    m = get_model(50, torch.bfloat16)
+    m.eval()
+    with torch.no_grad():
+        pred, saved = m([img, "keypoint_subnet"])
+        _, ds = m([img, "detection_subnet"])
+    ref = t(g["kp_pred_eval_2x128x128"])
+    rl2 = ((pred.float().cpu() - ref).norm() / ref.norm()).item()
+    report("bf16 vs reference fp32: kp pred rel-L2 %.3e" % rl2)
+    assert rl2 <= 3e-2
+    ref = t(g["det_reg_eval_2x128x128"])
+    rl2 = ((ds[1].float().cpu() - ref).norm() / ref.norm()).item()
+    report("bf16 vs reference fp32: det reg rel-L2 %.3e" % rl2)
+    assert rl2 <= 3e-2
+
+
+def test_full_size_batch_independence_and_determinism():
+    """BASELINE full size (R101, 480x480): size-independent properties — in eval mode an image's
+    outputs do not depend on its batch neighbours (bit-exact), and two runs are bit-identical."""
+    from oracle import weightgen
+    m = get_model(101, torch.bfloat16)
+    m.eval()
+    img = t(weightgen.gen_images(3, 4, 480, 480)).cuda()
+    with torch.no_grad():
+        p_all, _ = m([img, "keypoint_subnet"])
+        p_all2, _ = m([img, "keypoint_subnet"])
+        p_1, _ = m([img[1:2].contiguous(), "keypoint_subnet"])
+        _, d_all = m([img, "detection_subnet"])
+        _, d_1 = m([img[2:3].contiguous(), "detection_subnet"])
+    assert p_all.shape == (4, 18, 120, 120) and d_all[0].shape == (4, 43245, 1) and d_all[2].shape == (1, 43245, 4)
+    assert torch.equal(p_all, p_all2), "forward is not run-to-run deterministic"
+    assert torch.equal(p_all[1:2], p_1), "heat-map of image 1 depends on its batch neighbours"
+    assert torch.equal(d_all[1][2:3], d_1[1]) and torch.equal(d_all[0][2:3], d_1[0])
+    assert torch.isfinite(p_all).all() and torch.isfinite(d_all[1]).all()
+    report("full-size R101 480x480: batch independence + determinism OK")
