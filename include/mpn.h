@@ -113,15 +113,14 @@ int mpn_bn_act_forward(const void* y, const void* res, void* z, const float* sca
 /* backward, stage 1: g = dz * (z > 0 if relu); partial sums of g and g*xhat per channel */
 int mpn_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
                       float* partial, int chunks, int64_t P, int C, int Cs, int relu, int dtype, void* stream);
-/* backward, stage 2: reduce partials; dgamma += , dbeta += (if non-null); coef[c] = {a, b} */
-int mpn_bn_bwd_finalize(const float* partial, int chunks, int C, int64_t count, float* dgamma, float* dbeta,
-                        float* coef, void* stream);
-/* backward, stage 3: dy = gamma*invstd*(g - a - xhat*b) (train) or g*scale (frozen: coef==NULL);
- * dres (optional) receives / accumulates g */
-int mpn_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
-                     const float* gamma, const float* coef, void* dy, void* dres, int dres_accumulate,
-                     int64_t P, int C, int Cs, int relu, int dtype, void* stream);
-int mpn_bn_bwd_chunks(int64_t P, int C);
+/* backward, stage 2: reduce partials; dgamma += , dbeta += (if non-null); coef [3][C] = k1,k2,k3 with
+ * dy = k1*g + k2*y + k3  (train: full batch-stat backward; train=0: k1 = gamma*invstd, k2 = k3 = 0) */
+int mpn_bn_bwd_finalize(const float* partial, int chunks, int C, int64_t count, const float* gamma, const float* mean,
+                        const float* invstd, int train, float* dgamma, float* dbeta, float* coef, void* stream);
+/* backward, stage 3: dy = k1*g + k2*y + k3 (k2/k3 may be NULL = 0); dres (optional) receives / accumulates g */
+int mpn_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* k1, const float* k2, const float* k3,
+                     void* dy, void* dres, int dres_accumulate, int64_t P, int C, int Cs, int relu, int dtype, void* stream);
+int mpn_bn_bwd_chunks(int64_t P, int Cs, int dtype);
 
 /* ---------------------------------------------------------------------------------------------
  * Pooling / resampling / layout (fpn.py:84-100, posenet.py:180-184,296-315)
@@ -155,7 +154,7 @@ int mpn_relu_forward(const void* x, void* y, int64_t n, int dtype, void* stream)
 int mpn_relu_backward(const void* dz, const void* z, void* dx, int64_t n, int accumulate, int dtype, void* stream);
 int mpn_add_inplace(void* dst, const void* src, int64_t n, int dtype, void* stream);
 int mpn_channel_sum(const void* dy, int dy_dtype, int64_t P, int C, int Cs, float* partial, int chunks, void* stream);
-int mpn_channel_sum_chunks(int64_t P, int C);
+int mpn_channel_sum_chunks(int64_t P, int Cs, int dtype);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses (posenet.py:367-445, losses.py:5-137)

@@ -71,9 +71,9 @@ SIGNATURES = {
     "mpn_bn_finalize_eval": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "mpn_bn_act_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "mpn_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
-    "mpn_bn_bwd_finalize": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp]),
-    "mpn_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
-    "mpn_bn_bwd_chunks": (_i, [_i64, _i]),
+    "mpn_bn_bwd_finalize": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "mpn_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
+    "mpn_bn_bwd_chunks": (_i, [_i64, _i, _i]),
     "mpn_maxpool3x3s2_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mpn_maxpool3x3s2_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mpn_upsample_nearest_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -88,7 +88,7 @@ SIGNATURES = {
     "mpn_relu_backward": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "mpn_add_inplace": (_i, [_vp, _vp, _i64, _i, _vp]),
     "mpn_channel_sum": (_i, [_vp, _i, _i64, _i, _i, _vp, _i, _vp]),
-    "mpn_channel_sum_chunks": (_i, [_i64, _i]),
+    "mpn_channel_sum_chunks": (_i, [_i64, _i, _i]),
     "mpn_mse_chunks": (_i, [_i64]),
     "mpn_mse_heatmap_forward": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _i, _vp, _vp]),
     "mpn_mse_heatmap_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),

@@ -5,37 +5,66 @@
 // (network/posenet.py:220-224).  Semantics: eps 1e-5, momentum 0.1, biased variance to normalise,
 // unbiased variance into running_var (torch.nn.functional.batch_norm).
 //
-// All of these are HBM-bound streaming kernels: 16-byte vector loads/stores, one pass each.
+// All HBM-bound streaming kernels over dense pixel-major [P][Cs] tensors.  Thread mapping (all
+// kernels): a block is GB channel-groups (16 bytes = 8 bf16 / 4 f32 each) x (256/GB) pixel lanes;
+// a thread keeps ITS channel group's per-channel coefficients in registers (loaded once, as
+// float4s) and walks several pixels, so the stream is pure 16-byte coalesced loads/stores.
 //   train fwd : conv epilogue already produced per-tile (sum, sum^2) -> finalize -> bn_act pass
-//   backward  : reduce pass (sum g, sum g*xhat) -> finalize -> apply pass
+//   backward  : reduce pass (sum g, sum g*xhat) -> finalize (k1,k2,k3) -> apply pass dy=k1*g+k2*y+k3
 // Algorithmic bytes per element (bf16): bn_act 2+2(+2 res); bwd_reduce 6; bwd_apply 6+2(+2 dres).
 #include "common.h"
 
 namespace {
 
-constexpr int BN_CHUNK_PIX = 2048;
+template <typename T> struct Geo {
+    static constexpr int V = Vec16<T>::N;
+    int G, GB, lanes, g, pl, c0;
+    __device__ __forceinline__ Geo(int Cs) {
+        G = Cs / V;
+        GB = G < 256 ? G : 256;
+        lanes = 256 / GB;
+        g = blockIdx.y * GB + (threadIdx.x % GB);
+        pl = threadIdx.x / GB;
+        c0 = g * V;
+    }
+};
 
+template <int V>
+__device__ __forceinline__ void load_coef(const float* __restrict__ p, int c0, int C, float (&out)[V], float fill) {
+#pragma unroll
+    for (int k = 0; k < V; k += 4) {
+        if (p != nullptr && c0 + k + 3 < C) {
+            const float4 t = *reinterpret_cast<const float4*>(p + c0 + k);
+            out[k] = t.x; out[k + 1] = t.y; out[k + 2] = t.z; out[k + 3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[k + j] = (p != nullptr && c0 + k + j < C) ? p[c0 + k + j] : fill;
+        }
+    }
+}
+
+// block = 16 channels x 16 tile-slices
 __global__ void bn_finalize_train_kernel(const float* __restrict__ stats, int tiles, int C, double count,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                          float* __restrict__ rm, float* __restrict__ rv, float momentum, float eps,
                                          float* __restrict__ mean, float* __restrict__ invstd,
                                          float* __restrict__ scale, float* __restrict__ shift) {
-    // block = 64 channels x 4 tile-slices
-    __shared__ double sh[2][4][64];
-    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double sh[2][16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
-        for (int t = sl; t < tiles; t += 4) {
-            s1 += (double)stats[((long)t * C + c) * 2 + 0];
-            s2 += (double)stats[((long)t * C + c) * 2 + 1];
+        for (int t = sl; t < tiles; t += 16) {
+            const float2 v = *reinterpret_cast<const float2*>(stats + ((long)t * C + c) * 2);
+            s1 += (double)v.x; s2 += (double)v.y;
         }
     }
     sh[0][sl][cl] = s1; sh[1][sl][cl] = s2;
     __syncthreads();
     if (sl == 0 && c < C) {
-        s1 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
-        s2 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
+        s1 = 0.0; s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { s1 += sh[0][k][cl]; s2 += sh[1][k][cl]; }
         const double mu = s1 / count;
         double var = s2 / count - mu * mu;
         if (var < 0.0) var = 0.0;
@@ -63,57 +92,52 @@ __global__ void bn_finalize_eval_kernel(int C, const float* __restrict__ gamma, 
     mean[c] = rm[c]; invstd[c] = is; scale[c] = sc; shift[c] = beta[c] - rm[c] * sc;
 }
 
-// z = act(y*scale + shift + res); one 16-byte vector per thread
+// z = act(y*scale + shift + res)
 template <typename T>
-__global__ void bn_act_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ z,
-                              const float* __restrict__ scale, const float* __restrict__ shift,
-                              long nvec, int C, int Cs, int relu) {
+__global__ void __launch_bounds__(256) bn_act_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ z,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     long P, int C, int Cs, int relu, int iters) {
     constexpr int V = Vec16<T>::N;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nvec) return;
-    const int G = Cs / V;
-    const int c0 = (int)(i % G) * V;
-    Vec16<T> a; a.load(y + i * V);
-    Vec16<T> r;
-    if (res) r.load(res + i * V);
+    const Geo<T> q(Cs);
+    float sc[V], sf[V];
+    load_coef<V>(scale, q.c0, C, sc, 0.f);
+    load_coef<V>(shift, q.c0, C, sf, 0.f);
+    const long p0 = (long)blockIdx.x * q.lanes * iters + q.pl;
+    for (int it = 0; it < iters; ++it) {
+        const long p = p0 + (long)it * q.lanes;
+        if (p >= P) break;
+        const long off = p * Cs + q.c0;
+        Vec16<T> a; a.load(y + off);
+        Vec16<T> r;
+        if (res) r.load(res + off);
 #pragma unroll
-    for (int k = 0; k < V; ++k) {
-        const int c = c0 + k;
-        float x = 0.f;
-        if (c < C) {
-            x = a.v[k] * scale[c] + shift[c];
+        for (int k = 0; k < V; ++k) {
+            float x = a.v[k] * sc[k] + sf[k];
             if (res) x += r.v[k];
             if (relu) x = fmaxf(x, 0.f);
+            a.v[k] = (q.c0 + k < C) ? x : 0.f;
         }
-        a.v[k] = x;
+        a.store(z + off);
     }
-    a.store(z + i * V);
 }
 
 // stage 1 of backward: per (pixel-chunk, channel) partial sums of g and g*xhat
 template <typename T>
-__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ z, const T* __restrict__ y,
-                                     const float* __restrict__ mean, const float* __restrict__ invstd,
-                                     float* __restrict__ partial, long P, int C, int Cs, int relu) {
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ z, const T* __restrict__ y,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            float* __restrict__ partial, long P, int C, int Cs, int relu, int chunk_pix) {
     constexpr int V = Vec16<T>::N;
     __shared__ float sh[256][2 * V + 1];
-    const int G = Cs / V;                       // channel groups per pixel (power of two)
-    const int GB = G < 256 ? G : 256;           // groups handled by this block
-    const int lanes = 256 / GB;                 // pixel lanes
-    const int g = blockIdx.y * GB + (threadIdx.x % GB);
-    const int pl = threadIdx.x / GB;
-    const int c0 = g * V;
-    const long p_begin = (long)blockIdx.x * BN_CHUNK_PIX;
-    long p_end = p_begin + BN_CHUNK_PIX; if (p_end > P) p_end = P;
+    const Geo<T> q(Cs);
+    const long p_begin = (long)blockIdx.x * chunk_pix;
+    long p_end = p_begin + chunk_pix; if (p_end > P) p_end = P;
     float s1[V], s2[V], mu[V], is[V];
+    load_coef<V>(mean, q.c0, C, mu, 0.f);
+    load_coef<V>(invstd, q.c0, C, is, 0.f);
 #pragma unroll
-    for (int k = 0; k < V; ++k) {
-        s1[k] = 0.f; s2[k] = 0.f;
-        const int c = c0 + k;
-        mu[k] = c < C ? mean[c] : 0.f; is[k] = c < C ? invstd[c] : 0.f;
-    }
-    for (long p = p_begin + pl; p < p_end; p += lanes) {
-        const long off = p * Cs + c0;
+    for (int k = 0; k < V; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+    for (long p = p_begin + q.pl; p < p_end; p += q.lanes) {
+        const long off = p * Cs + q.c0;
         Vec16<T> d, o, x;
         d.load(dz + off); x.load(y + off);
         if (relu) o.load(z + off);
@@ -128,85 +152,109 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restri
 #pragma unroll
     for (int k = 0; k < V; ++k) { sh[threadIdx.x][k] = s1[k]; sh[threadIdx.x][V + k] = s2[k]; }
     __syncthreads();
-    if (pl == 0) {
-        for (int l = 1; l < lanes; ++l) {
+    if (q.pl == 0) {
+        for (int l = 1; l < q.lanes; ++l) {
 #pragma unroll
             for (int k = 0; k < V; ++k) {
-                s1[k] += sh[threadIdx.x + l * GB][k];
-                s2[k] += sh[threadIdx.x + l * GB][V + k];
+                s1[k] += sh[threadIdx.x + l * q.GB][k];
+                s2[k] += sh[threadIdx.x + l * q.GB][V + k];
             }
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            const int c = c0 + k;
-            if (c < C) {
-                partial[((long)blockIdx.x * C + c) * 2 + 0] = s1[k];
-                partial[((long)blockIdx.x * C + c) * 2 + 1] = s2[k];
-            }
+            const int c = q.c0 + k;
+            if (c < C) *reinterpret_cast<float2*>(partial + ((long)blockIdx.x * C + c) * 2) = make_float2(s1[k], s2[k]);
         }
     }
 }
 
+// reduce partials; dgamma/dbeta += ; coefficient vectors so that dy = k1*g + k2*y + k3:
+//   train : k1 = gamma*is, k2 = -gamma*is*is*b, k3 = gamma*is*(mu*is*b - a)   (a = sum g / n, b = sum g*xhat / n)
+//   frozen: k1 = gamma*is, k2 = k3 = 0
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C, double count,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
-    __shared__ double sh[2][4][64];
-    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+                                       const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                       int train, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+    __shared__ double sh[2][16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
-        for (int t = sl; t < chunks; t += 4) {
-            s1 += (double)partial[((long)t * C + c) * 2 + 0];
-            s2 += (double)partial[((long)t * C + c) * 2 + 1];
+        for (int t = sl; t < chunks; t += 16) {
+            const float2 v = *reinterpret_cast<const float2*>(partial + ((long)t * C + c) * 2);
+            s1 += (double)v.x; s2 += (double)v.y;
         }
     }
     sh[0][sl][cl] = s1; sh[1][sl][cl] = s2;
     __syncthreads();
     if (sl == 0 && c < C) {
-        s1 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
-        s2 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
+        s1 = 0.0; s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { s1 += sh[0][k][cl]; s2 += sh[1][k][cl]; }
         if (dbeta) dbeta[c] += (float)s1;
         if (dgamma) dgamma[c] += (float)s2;
-        if (coef) { coef[c * 2 + 0] = (float)(s1 / count); coef[c * 2 + 1] = (float)(s2 / count); }
+        if (coef) {
+            const float is = invstd[c], gm = gamma ? gamma[c] : 1.f, mu = mean[c];
+            const float a = (float)(s1 / count), b = (float)(s2 / count);
+            coef[c] = gm * is;
+            coef[C + c] = train ? -gm * is * is * b : 0.f;
+            coef[2 * C + c] = train ? gm * is * (mu * is * b - a) : 0.f;
+        }
     }
 }
 
+// dy = k1*g + k2*y + k3 ; dres (+)= g ; g = dz * (z > 0)
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ z, const T* __restrict__ y,
-                                    const float* __restrict__ mean, const float* __restrict__ invstd,
-                                    const float* __restrict__ gamma, const float* __restrict__ coef,
-                                    T* __restrict__ dy, T* __restrict__ dres, int dres_acc,
-                                    long nvec, int C, int Cs, int relu) {
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ z, const T* __restrict__ y,
+                                                           const float* __restrict__ k1p, const float* __restrict__ k2p,
+                                                           const float* __restrict__ k3p, T* __restrict__ dy, T* __restrict__ dres,
+                                                           int dres_acc, long P, int C, int Cs, int relu, int iters) {
     constexpr int V = Vec16<T>::N;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nvec) return;
-    const int G = Cs / V;
-    const int c0 = (int)(i % G) * V;
-    Vec16<T> d, o, x, out, r;
-    d.load(dz + i * V);
-    if (dy) x.load(y + i * V);
-    if (relu) o.load(z + i * V);
-    if (dres && dres_acc) r.load(dres + i * V);
+    const Geo<T> q(Cs);
+    float k1[V], k2[V], k3[V];
+    load_coef<V>(k1p, q.c0, C, k1, 0.f);
+    load_coef<V>(k2p, q.c0, C, k2, 0.f);
+    load_coef<V>(k3p, q.c0, C, k3, 0.f);
+    const bool need_y = (dy != nullptr) && (k2p != nullptr);
+    const long p0 = (long)blockIdx.x * q.lanes * iters + q.pl;
+    for (int it = 0; it < iters; ++it) {
+        const long p = p0 + (long)it * q.lanes;
+        if (p >= P) break;
+        const long off = p * Cs + q.c0;
+        Vec16<T> d, o, x, out, r;
+        d.load(dz + off);
+        if (need_y) x.load(y + off);
+        if (relu) o.load(z + off);
+        if (dres && dres_acc) r.load(dres + off);
 #pragma unroll
-    for (int k = 0; k < V; ++k) {
-        const int c = c0 + k;
-        float gk = d.v[k];
-        if (relu && !(o.v[k] > 0.f)) gk = 0.f;
-        float v = 0.f;
-        if (c < C && dy) {
-            const float is = invstd[c];
-            const float gm = gamma ? gamma[c] : 1.f;
-            if (coef) {
-                const float xh = (x.v[k] - mean[c]) * is;
-                v = gm * is * (gk - coef[c * 2 + 0] - xh * coef[c * 2 + 1]);
-            } else {
-                v = gk * gm * is;
-            }
+        for (int k = 0; k < V; ++k) {
+            float gk = d.v[k];
+            if (relu && !(o.v[k] > 0.f)) gk = 0.f;
+            const bool live = q.c0 + k < C;
+            out.v[k] = live ? (k1[k] * gk + (need_y ? k2[k] * x.v[k] : 0.f) + k3[k]) : 0.f;
+            if (dres) r.v[k] = (dres_acc ? r.v[k] : 0.f) + (live ? gk : 0.f);
         }
-        out.v[k] = v;
-        if (dres) r.v[k] = (dres_acc ? r.v[k] : 0.f) + (c < C ? gk : 0.f);
+        if (dy) out.store(dy + off);
+        if (dres) r.store(dres + off);
     }
-    if (dy) out.store(dy + i * V);
-    if (dres) r.store(dres + i * V);
+}
+
+inline int geo_lanes(int Cs, int V) { const int G = Cs / V; return 256 / (G < 256 ? G : 256); }
+inline int geo_yblocks(int Cs, int V) { const int G = Cs / V; return G <= 256 ? 1 : G / 256; }
+inline bool geo_ok(int Cs, int V) { const int G = Cs / V; return Cs % V == 0 && G > 0 && (G & (G - 1)) == 0; }
+
+// pixels per block for the streaming kernels: aim for >= ~8 blocks per CU, <= 16 pixels per thread
+inline int pick_iters(long P, int lanes) {
+    long it = P / ((long)lanes * 2048);
+    if (it < 1) it = 1;
+    if (it > 32) it = 32;
+    return (int)it;
+}
+inline int reduce_chunk(long P, int lanes) {
+    long c = P / 1024;                 // ~1024 chunks
+    const long lo = (long)lanes * 4, hi = 4096;
+    if (c < lo) c = lo;
+    if (c > hi) c = hi;
+    return (int)((c + lanes - 1) / lanes * lanes);
 }
 
 }  // namespace
@@ -215,7 +263,7 @@ extern "C" int mpn_bn_finalize_train(const float* stats, int tiles, int C, int64
                                      const float* beta, float* running_mean, float* running_var, float momentum,
                                      float eps, float* mean, float* invstd, float* scale, float* shift, void* stream) {
     MPN_CHECK_ARG(stats && tiles > 0 && C > 0 && count > 0 && mean && invstd && scale && shift);
-    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, stats, tiles, C,
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, stats, tiles, C,
                        (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
     return mpn_launch_status();
 }
@@ -231,67 +279,70 @@ extern "C" int mpn_bn_finalize_eval(int C, const float* gamma, const float* beta
 
 extern "C" int mpn_bn_act_forward(const void* y, const void* res, void* z, const float* scale, const float* shift,
                                   int64_t P, int C, int Cs, int relu, int dtype, void* stream) {
-    MPN_CHECK_ARG(y && z && scale && shift && P > 0 && C > 0 && Cs >= C && Cs % 8 == 0);
-    if (dtype == MPN_F32) {
-        const long nvec = (long)P * Cs / 4;
-        hipLaunchKernelGGL(bn_act_kernel<float>, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)y, (const float*)res, (float*)z, scale, shift, nvec, C, Cs, relu);
-    } else {
-        const long nvec = (long)P * Cs / 8;
-        hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)y, (const bf16_t*)res, (bf16_t*)z, scale, shift, nvec, C, Cs, relu);
-    }
+    MPN_CHECK_ARG(y && z && scale && shift && P > 0 && C > 0 && Cs >= C);
+    const int V = dtype == MPN_F32 ? 4 : 8;
+    MPN_CHECK_ARG(geo_ok(Cs, V) && C % 4 == 0);
+    const int lanes = geo_lanes(Cs, V), iters = pick_iters(P, lanes);
+    dim3 grid((unsigned)((P + (long)lanes * iters - 1) / ((long)lanes * iters)), (unsigned)geo_yblocks(Cs, V));
+    if (dtype == MPN_F32)
+        hipLaunchKernelGGL(bn_act_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, (const float*)res, (float*)z,
+                           scale, shift, (long)P, C, Cs, relu, iters);
+    else
+        hipLaunchKernelGGL(bn_act_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (const bf16_t*)res,
+                           (bf16_t*)z, scale, shift, (long)P, C, Cs, relu, iters);
     return mpn_launch_status();
 }
 
-extern "C" int mpn_bn_bwd_chunks(int64_t P, int C) {
-    (void)C;
-    return (int)((P + BN_CHUNK_PIX - 1) / BN_CHUNK_PIX);
+extern "C" int mpn_bn_bwd_chunks(int64_t P, int Cs, int dtype) {
+    const int V = dtype == MPN_F32 ? 4 : 8;
+    if (!geo_ok(Cs, V) || P <= 0) return MPN_E_BADARG;
+    const int chunk = reduce_chunk(P, geo_lanes(Cs, V));
+    return (int)((P + chunk - 1) / chunk);
 }
 
 extern "C" int mpn_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
                                  float* partial, int chunks, int64_t P, int C, int Cs, int relu, int dtype, void* stream) {
     MPN_CHECK_ARG(dz && y && mean && invstd && partial && P > 0 && C > 0 && Cs >= C);
     MPN_CHECK_ARG(!relu || z);
-    MPN_CHECK_ARG(chunks == (int)((P + BN_CHUNK_PIX - 1) / BN_CHUNK_PIX));
     const int V = dtype == MPN_F32 ? 4 : 8;
-    const int G = Cs / V;
-    MPN_CHECK_ARG(Cs % V == 0 && (G & (G - 1)) == 0);
-    const int GB = G < 256 ? G : 256;
-    dim3 grid((unsigned)chunks, (unsigned)(G / GB));
+    MPN_CHECK_ARG(geo_ok(Cs, V) && C % 4 == 0);
+    const int chunk = reduce_chunk(P, geo_lanes(Cs, V));
+    MPN_CHECK_ARG(chunks == (int)((P + chunk - 1) / chunk));
+    dim3 grid((unsigned)chunks, (unsigned)geo_yblocks(Cs, V));
     if (dtype == MPN_F32)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, (const float*)z,
-                           (const float*)y, mean, invstd, partial, (long)P, C, Cs, relu);
+                           (const float*)y, mean, invstd, partial, (long)P, C, Cs, relu, chunk);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz, (const bf16_t*)z,
-                           (const bf16_t*)y, mean, invstd, partial, (long)P, C, Cs, relu);
+                           (const bf16_t*)y, mean, invstd, partial, (long)P, C, Cs, relu, chunk);
     return mpn_launch_status();
 }
 
-extern "C" int mpn_bn_bwd_finalize(const float* partial, int chunks, int C, int64_t count, float* dgamma, float* dbeta,
-                                   float* coef, void* stream) {
+extern "C" int mpn_bn_bwd_finalize(const float* partial, int chunks, int C, int64_t count, const float* gamma, const float* mean,
+                                   const float* invstd, int train, float* dgamma, float* dbeta, float* coef, void* stream) {
     MPN_CHECK_ARG(partial && chunks > 0 && C > 0 && count > 0);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
-                       (double)count, dgamma, dbeta, coef);
+    MPN_CHECK_ARG(!coef || (mean && invstd));
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
+                       (double)count, gamma, mean, invstd, train, dgamma, dbeta, coef);
     return mpn_launch_status();
 }
 
-extern "C" int mpn_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
-                                const float* gamma, const float* coef, void* dy, void* dres, int dres_accumulate,
-                                int64_t P, int C, int Cs, int relu, int dtype, void* stream) {
-    MPN_CHECK_ARG(dz && (dy || dres) && P > 0 && C > 0 && Cs >= C && Cs % 8 == 0);
-    MPN_CHECK_ARG(!dy || (y && mean && invstd));
+extern "C" int mpn_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* k1, const float* k2, const float* k3,
+                                void* dy, void* dres, int dres_accumulate, int64_t P, int C, int Cs, int relu, int dtype,
+                                void* stream) {
+    MPN_CHECK_ARG(dz && (dy || dres) && P > 0 && C > 0 && Cs >= C);
+    MPN_CHECK_ARG(!dy || k1);
+    MPN_CHECK_ARG(!(dy && k2) || y);
     MPN_CHECK_ARG(!relu || z);
-    if (dtype == MPN_F32) {
-        const long nvec = (long)P * Cs / 4;
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)dz, (const float*)z, (const float*)y, mean, invstd, gamma, coef, (float*)dy, (float*)dres,
-                           dres_accumulate, nvec, C, Cs, relu);
-    } else {
-        const long nvec = (long)P * Cs / 8;
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, invstd, gamma, coef, (bf16_t*)dy,
-                           (bf16_t*)dres, dres_accumulate, nvec, C, Cs, relu);
-    }
+    const int V = dtype == MPN_F32 ? 4 : 8;
+    MPN_CHECK_ARG(geo_ok(Cs, V) && C % 4 == 0);
+    const int lanes = geo_lanes(Cs, V), iters = pick_iters(P, lanes);
+    dim3 grid((unsigned)((P + (long)lanes * iters - 1) / ((long)lanes * iters)), (unsigned)geo_yblocks(Cs, V));
+    if (dtype == MPN_F32)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, (const float*)z,
+                           (const float*)y, k1, k2, k3, (float*)dy, (float*)dres, dres_accumulate, (long)P, C, Cs, relu, iters);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz, (const bf16_t*)z,
+                           (const bf16_t*)y, k1, k2, k3, (bf16_t*)dy, (bf16_t*)dres, dres_accumulate, (long)P, C, Cs, relu, iters);
     return mpn_launch_status();
 }

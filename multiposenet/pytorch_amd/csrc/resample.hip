@@ -244,27 +244,48 @@ __global__ void add_inplace_kernel(T* __restrict__ dst, const T* __restrict__ sr
     a.store(dst + i * V);
 }
 
-constexpr int CS_CHUNK_PIX = 4096;
-// per-chunk column sums of dy[P][Cs] (bias gradients); partial[chunk][C]
+// per-chunk column sums of dy[P][Cs] (bias gradients); partial[chunk][C].  Same thread mapping as the
+// BN kernels: GB channel groups (16 B) x 256/GB pixel lanes, 16-byte coalesced loads.
 template <typename T>
-__global__ void channel_sum_kernel(const T* __restrict__ dy, long P, int C, int Cs, float* __restrict__ partial) {
-    __shared__ float sh[256];
-    // threads: lanes over channels (Cs <= 256 -> 256/Cs pixel lanes), generic scalar version
-    const int cpb = Cs < 256 ? Cs : 256;
-    const int lanes = 256 / cpb;
-    const int c = blockIdx.y * cpb + (threadIdx.x % cpb);
-    const int pl = threadIdx.x / cpb;
-    const long p_begin = (long)blockIdx.x * CS_CHUNK_PIX;
-    long p_end = p_begin + CS_CHUNK_PIX; if (p_end > P) p_end = P;
-    float s = 0.f;
-    if (pl < lanes && c < Cs)
-        for (long p = p_begin + pl; p < p_end; p += lanes) s += Elem<T>::ld(dy + p * Cs + c);
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    if (pl == 0 && c < C) {
-        for (int l = 1; l < lanes; ++l) s += sh[threadIdx.x + l * cpb];
-        partial[(long)blockIdx.x * C + c] = s;
+__global__ void __launch_bounds__(256) channel_sum_kernel(const T* __restrict__ dy, long P, int C, int Cs, float* __restrict__ partial, int chunk_pix) {
+    constexpr int V = Vec16<T>::N;
+    __shared__ float sh[256][V + 1];
+    const int G = Cs / V;
+    const int GB = G < 256 ? G : 256;
+    const int lanes = 256 / GB;
+    const int g = blockIdx.y * GB + (threadIdx.x % GB);
+    const int pl = threadIdx.x / GB;
+    const int c0 = g * V;
+    const long p_begin = (long)blockIdx.x * chunk_pix;
+    long p_end = p_begin + chunk_pix; if (p_end > P) p_end = P;
+    float s[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) s[k] = 0.f;
+    for (long p = p_begin + pl; p < p_end; p += lanes) {
+        Vec16<T> d; d.load(dy + p * Cs + c0);
+#pragma unroll
+        for (int k = 0; k < V; ++k) s[k] += d.v[k];
     }
+#pragma unroll
+    for (int k = 0; k < V; ++k) sh[threadIdx.x][k] = s[k];
+    __syncthreads();
+    if (pl == 0) {
+        for (int l = 1; l < lanes; ++l)
+#pragma unroll
+            for (int k = 0; k < V; ++k) s[k] += sh[threadIdx.x + l * GB][k];
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+            if (c0 + k < C) partial[(long)blockIdx.x * C + c0 + k] = s[k];
+    }
+}
+
+inline int cs_lanes(int Cs, int V) { const int G = Cs / V; return 256 / (G < 256 ? G : 256); }
+inline int cs_chunk(long P, int lanes) {
+    long c = P / 1024;
+    const long lo = (long)lanes * 4, hi = 4096;
+    if (c < lo) c = lo;
+    if (c > hi) c = hi;
+    return (int)((c + lanes - 1) / lanes * lanes);
 }
 
 inline unsigned nb(long n) { return (unsigned)((n + 255) / 256); }
@@ -390,15 +411,23 @@ extern "C" int mpn_add_inplace(void* dst, const void* src, int64_t n, int dtype,
     return mpn_launch_status();
 }
 
-extern "C" int mpn_channel_sum_chunks(int64_t P, int C) { (void)C; return (int)((P + CS_CHUNK_PIX - 1) / CS_CHUNK_PIX); }
+extern "C" int mpn_channel_sum_chunks(int64_t P, int Cs, int dtype) {
+    const int V = dtype == MPN_F32 ? 4 : 8;
+    const int G = Cs / V;
+    if (P <= 0 || Cs % V != 0 || G <= 0 || (G & (G - 1)) != 0) return MPN_E_BADARG;
+    const int chunk = cs_chunk(P, cs_lanes(Cs, V));
+    return (int)((P + chunk - 1) / chunk);
+}
 
 extern "C" int mpn_channel_sum(const void* dy, int dy_dtype, int64_t P, int C, int Cs, float* partial, int chunks, void* stream) {
     MPN_CHECK_ARG(dy && partial && P > 0 && C > 0 && Cs >= C);
-    MPN_CHECK_ARG(chunks == (int)((P + CS_CHUNK_PIX - 1) / CS_CHUNK_PIX));
-    MPN_CHECK_ARG(Cs <= 256 ? (256 % Cs == 0) : (Cs % 256 == 0));
-    const int cpb = Cs < 256 ? Cs : 256;
-    dim3 grid((unsigned)chunks, (unsigned)((Cs + cpb - 1) / cpb));
-    if (dy_dtype == MPN_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy, (long)P, C, Cs, partial);
-    else hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (long)P, C, Cs, partial);
+    const int V = dy_dtype == MPN_F32 ? 4 : 8;
+    const int G = Cs / V;
+    MPN_CHECK_ARG(Cs % V == 0 && G > 0 && (G & (G - 1)) == 0);
+    const int chunk = cs_chunk(P, cs_lanes(Cs, V));
+    MPN_CHECK_ARG(chunks == (int)((P + chunk - 1) / chunk));
+    dim3 grid((unsigned)chunks, (unsigned)(G <= 256 ? 1 : G / 256));
+    if (dy_dtype == MPN_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy, (long)P, C, Cs, partial, chunk);
+    else hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (long)P, C, Cs, partial, chunk);
     return mpn_launch_status();
 }

@@ -225,7 +225,7 @@ def conv_wgrad(x, dy, dw, Cout, R, S, stride, pad, cin=None, x_geom=None):
 
 def bias_grad(dy, db, C):
     """db[C] (f32) += column sums of dy."""
-    chunks = call("mpn_channel_sum_chunks", dy.P, C)
+    chunks = call("mpn_channel_sum_chunks", dy.P, dy.Cs, dtype_code(dy.t.dtype))
     ws = workspace(chunks * C * 4, dy.t.device, slot=2)
     call("mpn_channel_sum", ptr(dy.t), dtype_code(dy.t.dtype), dy.P, C, dy.Cs, ptr(ws), chunks, stream_ptr())
     call("mpn_reduce_partials", ptr(ws), chunks, C, ptr(db), 1, stream_ptr())
@@ -275,21 +275,23 @@ def bn_backward(dz, z, y, st, gamma, relu, train, dgamma=None, dbeta=None, want_
     dev = y.t.device
     P, C, Cs = y.P, y.C, y.Cs
     dc = dtype_code(y.t.dtype)
-    coef = None
+    k1, k2, k3 = st.scale, None, None        # frozen BN, no parameter gradients: dy = g * gamma * invstd
     if train or dgamma is not None or dbeta is not None:
-        chunks = call("mpn_bn_bwd_chunks", P, C)
+        chunks = call("mpn_bn_bwd_chunks", P, Cs, dc)
         part = workspace(chunks * C * 2 * 4, dev, slot=3)
         call("mpn_bn_bwd_reduce", ptr(dz.t), ptr(z.t) if relu else None, ptr(y.t), ptr(st.mean), ptr(st.invstd), ptr(part),
              chunks, P, C, Cs, 1 if relu else 0, dc, stream_ptr())
+        coef = torch.empty((3, C), dtype=torch.float32, device=dev) if train else None
+        call("mpn_bn_bwd_finalize", ptr(part), chunks, C, P, ptr(gamma), ptr(st.mean), ptr(st.invstd), 1 if train else 0,
+             ptr(dgamma), ptr(dbeta), ptr(coef), stream_ptr())
         if train:
-            coef = torch.empty((C, 2), dtype=torch.float32, device=dev)
-        call("mpn_bn_bwd_finalize", ptr(part), chunks, C, P, ptr(dgamma), ptr(dbeta), ptr(coef), stream_ptr())
+            k1, k2, k3 = coef[0], coef[1], coef[2]
     dy = None
     if want_dy or dres is not None:
         if want_dy:
             dy = Act(torch.empty_like(y.t), C)
-        call("mpn_bn_bwd_apply", ptr(dz.t), ptr(z.t) if relu else None, ptr(y.t), ptr(st.mean), ptr(st.invstd), ptr(gamma),
-             ptr(coef), ptr(dy.t) if dy is not None else None, ptr(dres.t) if dres is not None else None,
+        call("mpn_bn_bwd_apply", ptr(dz.t), ptr(z.t) if relu else None, ptr(y.t), ptr(k1), ptr(k2), ptr(k3),
+             ptr(dy.t) if dy is not None else None, ptr(dres.t) if dres is not None else None,
              1 if dres_acc else 0, P, C, Cs, 1 if relu else 0, dc, stream_ptr())
     return dy
 
