@@ -250,7 +250,7 @@ inline int pick_iters(long P, int lanes) {
     return (int)it;
 }
 inline int reduce_chunk(long P, int lanes) {
-    long c = P / 1024;                 // ~1024 chunks
+    long c = P / 512;                  // ~512 chunks
     const long lo = (long)lanes * 4, hi = 4096;
     if (c < lo) c = lo;
     if (c > hi) c = hi;

@@ -91,8 +91,8 @@ template <typename T, typename OT, int TC, int TP>
 __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&acc)[ConvCfg<T, TC, TP>::MC][ConvCfg<T, TC, TP>::MP],
                                               int c0, long p0, int wc, int wp, int lane, int tp, float* lds_f) {
     using C = ConvCfg<T, TC, TP>;
-    const long HoWo = (long)p.Ho * p.Wo;
-    const long P = (long)p.B * HoWo;
+    const unsigned HoWo = (unsigned)p.Ho * (unsigned)p.Wo;
+    const unsigned P = (unsigned)p.B * HoWo;           // launcher guarantees P < 2^31
     OT* __restrict__ Y = (OT*)p.y;
     const OT* __restrict__ Rz = (const OT*)p.res;
     const int lrow4 = (lane >> 4) * 4;
@@ -106,19 +106,19 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
 
 #pragma unroll
     for (int j = 0; j < C::MP; ++j) {
-        const long pix = p0 + wp * C::WTP + j * 16 + lcol;
+        const unsigned pix = (unsigned)p0 + wp * C::WTP + j * 16 + lcol;
         const bool pok = pix < P;
-        const long pc = pok ? pix : 0;
-        const long b = pc / HoWo;
-        const long rem = pc - b * HoWo;
-        const long yoff = b * p.y_sB + rem * p.y_sP;
+        const unsigned pc = pok ? pix : 0u;
+        const unsigned b = pc / HoWo;
+        const unsigned rem = pc - b * HoWo;
+        const long yoff = (long)b * p.y_sB + (long)rem * p.y_sP;
         long roff = 0;
         if (p.res_mode == 1) {
-            roff = b * p.res_sB + rem * p.res_sP;
+            roff = (long)b * p.res_sB + (long)rem * p.res_sP;
         } else if (p.res_mode == 2) {
-            const int ho = (int)(rem / p.Wo), wo = (int)(rem - (long)ho * p.Wo);
-            const int rh = (int)(((long)ho * p.res_H) / p.Ho), rw = (int)(((long)wo * p.res_W) / p.Wo);
-            roff = b * p.res_sB + ((long)rh * p.res_W + rw) * p.res_sP;
+            const unsigned ho = rem / (unsigned)p.Wo, wo = rem - ho * (unsigned)p.Wo;
+            const unsigned rh = (ho * (unsigned)p.res_H) / (unsigned)p.Ho, rw = (wo * (unsigned)p.res_W) / (unsigned)p.Wo;
+            roff = (long)b * p.res_sB + (long)(rh * (unsigned)p.res_W + rw) * p.res_sP;
         }
 #pragma unroll
         for (int i = 0; i < C::MC; ++i) {
@@ -198,15 +198,15 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
 }
 
 template <typename T, int TC, int TP>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const MpnConvParams p) {
+__global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams p) {
     using C = ConvCfg<T, TC, TP>;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * C::BUF_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave / C::WAVES_P, wp = wave % C::WAVES_P;
     const int tilesC = (p.Cout_store + TC - 1) / TC;
-    const long HoWo = (long)p.Ho * p.Wo;
-    const long P = (long)p.B * HoWo;
+    const unsigned HoWo = (unsigned)p.Ho * (unsigned)p.Wo;
+    const unsigned P = (unsigned)p.B * HoWo;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tp = bid / tilesC, tc = bid - tp * tilesC;
     const long p0 = (long)tp * TP;
@@ -236,16 +236,16 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const MpnConvParams p) 
     for (int q = 0; q < C::B_PER_T; ++q) {
         const int u = tid + 256 * q;
         const int row = u >> 2, ch = u & 3;
-        const long pix = p0 + row;
+        const unsigned pix = (unsigned)p0 + row;
         const bool ok = (u < TP * 4) && (pix < P);
-        const long pc = ok ? pix : 0;
-        const long b = pc / HoWo;
-        const long rem = pc - b * HoWo;
-        const int ho = (int)(rem / p.Wo), wo = (int)(rem - (long)ho * p.Wo);
+        const unsigned pc = ok ? pix : 0u;
+        const unsigned b = pc / HoWo;
+        const unsigned rem = pc - b * HoWo;
+        const int ho = (int)(rem / (unsigned)p.Wo), wo = (int)(rem - (unsigned)ho * (unsigned)p.Wo);
         b_ok[q] = ok;
         if (p.mode == 0) { b_h[q] = ho * p.stride - p.pad; b_w[q] = wo * p.stride - p.pad; }
         else             { b_h[q] = ho + p.pad;            b_w[q] = wo + p.pad; }
-        b_base[q] = b * p.x_sB + ch * C::V;
+        b_base[q] = (long)b * p.x_sB + ch * C::V;
         b_lds[q] = (u < TP * 4) ? (TC + row) * LDS_ROW + ch * 16 : -1;
     }
 
@@ -258,10 +258,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const MpnConvParams p) 
     const int nsteps = p.R * p.S * (p.Cin / C::KC);
     int r = 0, s = 0, cc = 0;
     long klin = 0;
-    u32x4_t ra[C::A_PER_T], rb[C::B_PER_T];
+    // two register stages: loads run TWO k-steps ahead of the MFMAs (global latency ~1 us per hop is the
+    // critical path of a short k-step; one stage in flight while the other is written to LDS)
+    u32x4_t ra0[C::A_PER_T], rb0[C::B_PER_T], ra1[C::A_PER_T], rb1[C::B_PER_T];
     const u32x4_t zero4 = (u32x4_t){0u, 0u, 0u, 0u};
 
-    auto gload = [&]() {
+    auto gload = [&](u32x4_t (&ra)[C::A_PER_T], u32x4_t (&rb)[C::B_PER_T]) {
 #pragma unroll
         for (int q = 0; q < C::A_PER_T; ++q)
             ra[q] = a_ok[q] ? *reinterpret_cast<const u32x4_t*>(Wg + a_off[q] + klin) : zero4;
@@ -284,7 +286,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const MpnConvParams p) 
         klin += C::KC; cc += C::KC;
         if (cc == p.Cin) { cc = 0; if (++s == p.S) { s = 0; ++r; } }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const u32x4_t (&ra)[C::A_PER_T], const u32x4_t (&rb)[C::B_PER_T]) {
         unsigned char* base = lds + buf * C::BUF_BYTES;
 #pragma unroll
         for (int q = 0; q < C::A_PER_T; ++q)
@@ -293,16 +295,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const MpnConvParams p) 
         for (int q = 0; q < C::B_PER_T; ++q)
             if (b_lds[q] >= 0) *reinterpret_cast<u32x4_t*>(base + b_lds[q]) = rb[q];
     };
-
-    gload();
-    lstore(0);
-    __syncthreads();
     const int fa_off = (wc * C::WTC + (lane & 15)) * LDS_ROW + (lane >> 4) * 16;
     const int fb_off = (TC + wp * C::WTP + (lane & 15)) * LDS_ROW + (lane >> 4) * 16;
-    for (int it = 0; it < nsteps; ++it) {
-        const bool more = (it + 1) < nsteps;
-        if (more) gload();
-        const unsigned char* base = lds + (it & 1) * C::BUF_BYTES;
+    auto compute = [&](int buf) {
+        const unsigned char* base = lds + buf * C::BUF_BYTES;
         u32x4_t fa[C::MC], fb[C::MP];
 #pragma unroll
         for (int i = 0; i < C::MC; ++i)
@@ -314,9 +310,25 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const MpnConvParams p) 
         for (int i = 0; i < C::MC; ++i)
 #pragma unroll
             for (int j = 0; j < C::MP; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
-        if (more) lstore((it + 1) & 1);
+    };
+
+    gload(ra0, rb0);
+    if (nsteps > 1) gload(ra1, rb1);
+    lstore(0, ra0, rb0);
+    __syncthreads();
+    int it = 0;
+    for (; it + 1 < nsteps; it += 2) {
+        if (it + 2 < nsteps) gload(ra0, rb0);       // step it+2
+        compute(0);                                  // step it
+        lstore(1, ra1, rb1);                         // step it+1 (loaded one half-iteration ago)
+        __syncthreads();
+        if (it + 3 < nsteps) gload(ra1, rb1);       // step it+3
+        compute(1);                                  // step it+1
+        if (it + 2 < nsteps) lstore(0, ra0, rb0);   // step it+2
         __syncthreads();
     }
+    if (it < nsteps) compute(0);
+    __syncthreads();
 
     float* lds_f = reinterpret_cast<float*>(lds);
     if (p.out_f32) conv_epilogue<T, float, TC, TP>(p, acc, c0, p0, wc, wp, lane, tp, lds_f);
@@ -325,16 +337,22 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const MpnConvParams p) 
 
 constexpr int kTP = 128;
 
-inline int pick_tc(int cout_store) { return cout_store > 64 ? 128 : (cout_store > 32 ? 64 : 32); }
+inline int pick_tc(int cout_store, long tilesP) {
+    if (cout_store <= 32) return 32;
+    if (cout_store <= 64) return 64;
+    // 128-row tiles unless that leaves the 256 CUs with fewer than ~3 workgroups each
+    const long blocks128 = tilesP * ((cout_store + 127) / 128);
+    return blocks128 >= 768 ? 128 : 64;
+}
 
 template <typename T>
 int launch_conv(const MpnConvParams& p, hipStream_t st) {
     const long P = (long)p.B * p.Ho * p.Wo;
     const long tilesP = (P + kTP - 1) / kTP;
-    const int tc = pick_tc(p.Cout_store);
+    const int tc = pick_tc(p.Cout_store, tilesP);
     const long tilesC = (p.Cout_store + tc - 1) / tc;
     const long grid = tilesP * tilesC;
-    if (grid <= 0 || grid > 0x7fffffffL) return MPN_E_BADARG;
+    if (grid <= 0 || grid > 0x7fffffffL || P >= 0x7fffffffL) return MPN_E_BADARG;
     if (tc == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, kTP>), dim3((unsigned)grid), dim3(256), 0, st, p);
     else if (tc == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, kTP>), dim3((unsigned)grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((conv_igemm_kernel<T, 32, kTP>), dim3((unsigned)grid), dim3(256), 0, st, p);

@@ -24,12 +24,13 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 struct PixState {      // incremental (b, ho, wo) walker over the dense output-pixel index
     int b, ho, wo;
-    __device__ __forceinline__ void init(long pix, int Ho, int Wo) {
-        const long hw = (long)Ho * Wo;
-        b = (int)(pix / hw);
-        const long rem = pix - (long)b * hw;
-        ho = (int)(rem / Wo);
-        wo = (int)(rem - (long)ho * Wo);
+    __device__ __forceinline__ void init(long pix, int Ho, int Wo) {      // pix < 2^31 (checked by the launcher)
+        const unsigned hw = (unsigned)Ho * (unsigned)Wo;
+        const unsigned px = (unsigned)pix;
+        const unsigned bb = px / hw;
+        const unsigned rem = px - bb * hw;
+        const unsigned hh = rem / (unsigned)Wo;
+        b = (int)bb; ho = (int)hh; wo = (int)(rem - hh * (unsigned)Wo);
     }
     __device__ __forceinline__ void advance(int n, int Ho, int Wo) {
         wo += n;
@@ -61,7 +62,7 @@ struct WgCfg {
 };
 
 template <typename T, int TM, int TN>
-__global__ void __launch_bounds__(256) conv_wgrad_kernel(const MpnWgradParams p, long chunk_pixels) {
+__global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(const MpnWgradParams p, long chunk_pixels) {
     using C = WgCfg<T, TM, TN>;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * C::BUF_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -111,7 +112,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const MpnWgradParams p,
         for (int j = 0; j < C::MN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     constexpr int NR = C::kBf16 ? 2 : 1;      // pixel rows per unit
-    u32x4_t ra[C::A_PER_T][NR], rb[C::B_PER_T][NR];
+    u32x4_t ra0[C::A_PER_T][NR], rb0[C::B_PER_T][NR], ra1[C::A_PER_T][NR], rb1[C::B_PER_T][NR];   // loads run two k-steps ahead
     const u32x4_t zero4 = (u32x4_t){0u, 0u, 0u, 0u};
     long k0 = k_begin;
 
@@ -121,7 +122,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const MpnWgradParams p,
         const long off = (long)ps.b * p.x_sB + (long)hi * p.x_sH + (long)wi * p.x_sW + m0 + c;
         return ok ? *reinterpret_cast<const u32x4_t*>(X + off) : zero4;
     };
-    auto gload = [&]() {
+    auto gload = [&](u32x4_t (&ra)[C::A_PER_T][NR], u32x4_t (&rb)[C::B_PER_T][NR]) {
 #pragma unroll
         for (int q = 0; q < C::A_PER_T; ++q) {
             if (a_on[q]) {
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const MpnWgradParams p,
         }
         k0 += C::KP;
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const u32x4_t (&ra)[C::A_PER_T][NR], const u32x4_t (&rb)[C::B_PER_T][NR]) {
         unsigned char* la = lds + buf * C::BUF_BYTES;
         unsigned char* lb = la + C::A_BYTES;
         if (C::kBf16) {
@@ -187,15 +188,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const MpnWgradParams p,
 
     const long span = k_end - k_begin;
     const int nsteps = span > 0 ? (int)((span + C::KP - 1) / C::KP) : 0;
-    if (nsteps > 0) {
-        gload();
-        lstore(0);
-    }
-    __syncthreads();
-    for (int it = 0; it < nsteps; ++it) {
-        const bool more = (it + 1) < nsteps;
-        if (more) gload();
-        const unsigned char* la = lds + (it & 1) * C::BUF_BYTES;
+    auto compute = [&](int buf) {
+        const unsigned char* la = lds + buf * C::BUF_BYTES;
         const unsigned char* lb = la + C::A_BYTES;
         if (C::kBf16) {
             u32x4_t fa[C::MM], fb[C::MN];
@@ -229,9 +223,25 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const MpnWgradParams p,
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (more) lstore((it + 1) & 1);
+    };
+    if (nsteps > 0) {
+        gload(ra0, rb0);
+        if (nsteps > 1) gload(ra1, rb1);
+        lstore(0, ra0, rb0);
+    }
+    __syncthreads();
+    int it = 0;
+    for (; it + 1 < nsteps; it += 2) {
+        if (it + 2 < nsteps) gload(ra0, rb0);
+        compute(0);
+        lstore(1, ra1, rb1);
+        __syncthreads();
+        if (it + 3 < nsteps) gload(ra1, rb1);
+        compute(1);
+        if (it + 2 < nsteps) lstore(0, ra0, rb0);
         __syncthreads();
     }
+    if (it < nsteps) compute(0);
 
     // ---------------- epilogue ----------------
     const long NW = (long)p.Cout * taps * p.Cin;
@@ -277,6 +287,24 @@ __global__ void reduce_partials_kernel(const float* __restrict__ ws, int chunks,
     }
 }
 
+// small n (bias gradients: n = channels, many chunks): 16 outputs x 16 chunk-slices per block
+__global__ void reduce_partials_small_kernel(const float* __restrict__ ws, int chunks, long n, float* __restrict__ dst, int accumulate) {
+    __shared__ float sh[16][17];
+    const int ol = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + ol;
+    float a = 0.f;
+    if (i < n)
+        for (int c = sl; c < chunks; c += 16) a += ws[(long)c * n + i];
+    sh[sl][ol] = a;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        a = accumulate ? dst[i] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += sh[k][ol];
+        dst[i] = a;
+    }
+}
+
 inline int pick_tile(int n) { return n > 64 ? 128 : (n > 32 ? 64 : 32); }
 
 template <typename T, int TM>
@@ -296,7 +324,7 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st) {
     long chunk_pixels = (P + p.chunks - 1) / p.chunks;
     chunk_pixels = ((chunk_pixels + kp - 1) / kp) * kp;
     const long grid = tilesM * tilesN * p.R * p.S * p.chunks;
-    if (grid <= 0 || grid > 0x7fffffffL) return MPN_E_BADARG;
+    if (grid <= 0 || grid > 0x7fffffffL || P >= 0x7fffffffL) return MPN_E_BADARG;
     int rc;
     if (tm == 128) rc = launch_wgrad_n<T, 128>(p, tn, grid, chunk_pixels, st);
     else if (tm == 64) rc = launch_wgrad_n<T, 64>(p, tn, grid, chunk_pixels, st);
@@ -342,6 +370,11 @@ extern "C" int mpn_conv_wgrad(const MpnWgradParams* pp, void* stream) {
 
 extern "C" int mpn_reduce_partials(const float* ws, int chunks, int64_t n, float* dst, int accumulate, void* stream) {
     MPN_CHECK_ARG(ws && dst && chunks >= 1 && n > 0);
+    if (n <= 8192 && chunks >= 32) {
+        hipLaunchKernelGGL(reduce_partials_small_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+                           ws, chunks, (long)n, dst, accumulate);
+        return mpn_launch_status();
+    }
     const long threads = (n + 3) / 4;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        ws, chunks, (long)n, dst, accumulate);

@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256) channel_sum_kernel(const T* __restrict__ 
 
 inline int cs_lanes(int Cs, int V) { const int G = Cs / V; return 256 / (G < 256 ? G : 256); }
 inline int cs_chunk(long P, int lanes) {
-    long c = P / 1024;
+    long c = P / 512;
     const long lo = (long)lanes * 4, hi = 4096;
     if (c < lo) c = lo;
     if (c > hi) c = hi;

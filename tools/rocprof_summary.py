@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace rocpd database (…_results.db) into a per-kernel table.
+
+usage: python tools/rocprof_summary.py gpurun_out/prof2/prof2_results.db STEPS "title" > profiles/rNN_….txt
+"""
+import re
+import sqlite3
+import sys
+
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    n = n.replace("unsigned short", "bf16")
+    return n[:96]
+
+
+def main():
+    db, steps, title = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3 "
+                       "from kernels group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows)
+    print("# %s" % title)
+    print("# source: rocprofv3 --kernel-trace --stats (rocpd sqlite), %d steps; total kernel time %.1f ms = %.2f ms/step" % (steps, tot, tot / steps))
+    print("%-98s %7s %10s %9s %9s %9s %6s" % ("kernel", "calls", "total_ms", "ms/step", "avg_us", "max_us", "pct"))
+    for r in rows:
+        if r[2] / tot < 0.0002:
+            continue
+        print("%-98s %7d %10.2f %9.3f %9.1f %9.1f %6.2f" % (short(r[0]), r[1], r[2], r[2] / steps, r[3], r[5], 100 * r[2] / tot))
+    for kn in ("conv_igemm_kernel<unsigned short, 128, 128>", "conv_igemm_kernel<unsigned short, 64, 128>", "conv_wgrad_kernel<unsigned short, 128, 128>"):
+        g = cur.execute("select grid_x/workgroup_x, count(*), sum(end-start)/1e6, avg(end-start)/1e3 from kernels where name like ? "
+                        "group by grid_x order by 3 desc", ("%" + kn + "%",)).fetchall()
+        if not g:
+            continue
+        print("\n# %s by launch geometry (workgroups)" % short(kn))
+        for r in g[:14]:
+            print("  blocks=%7d calls/step=%6.1f  ms/step=%8.3f  avg=%9.1f us" % (r[0], r[1] / steps, r[2] / steps, r[3]))
+
+
+if __name__ == "__main__":
+    main()
