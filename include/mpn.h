@@ -57,6 +57,8 @@ typedef struct MpnConvParams {
 
 /* number of pixel tiles (rows of `stats`) mpn_conv_forward will use for this problem */
 int mpn_conv_stats_tiles(const MpnConvParams* p);
+/* output-channel rows of the tile (128 / 64 / 32) the launcher will pick: names the kernel instantiation */
+int mpn_conv_tile_rows(const MpnConvParams* p);
 int mpn_conv_forward(const MpnConvParams* p, void* stream);
 
 typedef struct MpnWgradParams {

@@ -57,6 +57,7 @@ _PW = ctypes.POINTER(WgradParams)
 # against the header and against the exported dynamic symbols).
 SIGNATURES = {
     "mpn_conv_stats_tiles": (_i, [_PC]),
+    "mpn_conv_tile_rows": (_i, [_PC]),
     "mpn_conv_forward": (_i, [_PC, _vp]),
     "mpn_conv_wgrad_chunks": (_i, [_PW]),
     "mpn_conv_wgrad": (_i, [_PW, _vp]),
@@ -112,7 +113,7 @@ SIGNATURES = {
 }
 
 # entry points that return a count, not a status
-_COUNT_FUNCS = {"mpn_conv_stats_tiles", "mpn_conv_wgrad_chunks", "mpn_bn_bwd_chunks", "mpn_channel_sum_chunks",
+_COUNT_FUNCS = {"mpn_conv_stats_tiles", "mpn_conv_tile_rows", "mpn_conv_wgrad_chunks", "mpn_bn_bwd_chunks", "mpn_channel_sum_chunks",
                 "mpn_mse_chunks", "mpn_focal_blocks", "mpn_bce_chunks", "mpn_nms_workspace_bytes", "mpn_version"}
 
 _lib = None

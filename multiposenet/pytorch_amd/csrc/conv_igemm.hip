@@ -87,52 +87,63 @@ struct ConvCfg {
     static constexpr int BUF_BYTES = (TC + TP) * LDS_ROW;
 };
 
+// Epilogue.  Phase A (accumulator layout: lane = 4 consecutive couts of one pixel): scale, bias, residual,
+// accumulate, activation, BN partial sums.  Phase B: the finished tile goes through a per-wave LDS staging
+// area and leaves as 16-byte stores with 8..16 lanes covering one pixel's contiguous channels (full 128-byte
+// lines per wave-instruction) instead of 16 strided 8-byte stores per lane.
 template <typename T, typename OT, int TC, int TP>
 __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&acc)[ConvCfg<T, TC, TP>::MC][ConvCfg<T, TC, TP>::MP],
-                                              int c0, long p0, int wc, int wp, int lane, int tp, float* lds_f) {
+                                              int c0, long p0, int wc, int wp, int lane, int tp, unsigned char* lds) {
     using C = ConvCfg<T, TC, TP>;
+    constexpr int OSZ = (int)sizeof(OT);
+    constexpr int PASS_TILES = (OSZ == 4) ? ((C::MP >= 2) ? C::MP / 2 : 1) : C::MP;   // pixel tiles staged per pass
+    constexpr int NPASS = C::MP / PASS_TILES;
+    constexpr int SROW = C::WTC * OSZ + 16;                   // staging row stride (bytes)
+    constexpr int REGION = PASS_TILES * 16 * SROW;            // per wave
+    constexpr int LPP = C::WTC * OSZ / 16;                    // lanes per pixel in the store phase
+    constexpr int PPI = 64 / LPP;                             // pixels per store instruction
+    constexpr int EV = 16 / OSZ;                              // elements per 16-byte store
+    static_assert(4 * REGION <= 2 * C::BUF_BYTES, "staging area must fit the main-loop LDS");
     const unsigned HoWo = (unsigned)p.Ho * (unsigned)p.Wo;
     const unsigned P = (unsigned)p.B * HoWo;           // launcher guarantees P < 2^31
     OT* __restrict__ Y = (OT*)p.y;
     const OT* __restrict__ Rz = (const OT*)p.res;
     const int lrow4 = (lane >> 4) * 4;
     const int lcol = lane & 15;
+    float* lds_f = reinterpret_cast<float*>(lds);
 
-    float s1[C::MC][4], s2[C::MC][4];
-#pragma unroll
-    for (int i = 0; i < C::MC; ++i)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { s1[i][c] = 0.f; s2[i][c] = 0.f; }
-
+    // ---- phase A: finish the values in registers -------------------------------------------------
+    const bool simple = (p.res_mode == 0) && !p.accumulate;
 #pragma unroll
     for (int j = 0; j < C::MP; ++j) {
         const unsigned pix = (unsigned)p0 + wp * C::WTP + j * 16 + lcol;
         const bool pok = pix < P;
-        const unsigned pc = pok ? pix : 0u;
-        const unsigned b = pc / HoWo;
-        const unsigned rem = pc - b * HoWo;
-        const long yoff = (long)b * p.y_sB + (long)rem * p.y_sP;
-        long roff = 0;
-        if (p.res_mode == 1) {
-            roff = (long)b * p.res_sB + (long)rem * p.res_sP;
-        } else if (p.res_mode == 2) {
-            const unsigned ho = rem / (unsigned)p.Wo, wo = rem - ho * (unsigned)p.Wo;
-            const unsigned rh = (ho * (unsigned)p.res_H) / (unsigned)p.Ho, rw = (wo * (unsigned)p.res_W) / (unsigned)p.Wo;
-            roff = (long)b * p.res_sB + (long)(rh * (unsigned)p.res_W + rw) * p.res_sP;
+        long yoff = 0, roff = 0;
+        if (!simple) {
+            const unsigned pc = pok ? pix : 0u;
+            const unsigned b = pc / HoWo;
+            const unsigned rem = pc - b * HoWo;
+            yoff = (long)b * p.y_sB + (long)rem * p.y_sP;
+            if (p.res_mode == 1) {
+                roff = (long)b * p.res_sB + (long)rem * p.res_sP;
+            } else if (p.res_mode == 2) {
+                const unsigned ho = rem / (unsigned)p.Wo, wo = rem - ho * (unsigned)p.Wo;
+                const unsigned rh = (ho * (unsigned)p.res_H) / (unsigned)p.Ho, rw = (wo * (unsigned)p.res_W) / (unsigned)p.Wo;
+                roff = (long)b * p.res_sB + (long)(rh * (unsigned)p.res_W + rw) * p.res_sP;
+            }
         }
 #pragma unroll
         for (int i = 0; i < C::MC; ++i) {
             const int cout0 = c0 + wc * C::WTC + i * 16 + lrow4;
-            if (cout0 >= p.Cout_store) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             float rv[4] = {0.f, 0.f, 0.f, 0.f};
             float yv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (pok && p.res_mode != 0) OutVec4<OT>::load(Rz + roff + cout0, rv);
-            if (pok && p.accumulate) OutVec4<OT>::load(Y + yoff + cout0, yv);
+            const bool live = pok && cout0 < p.Cout_store;
+            if (live && p.res_mode != 0) OutVec4<OT>::load(Rz + roff + cout0, rv);
+            if (live && p.accumulate) OutVec4<OT>::load(Y + yoff + cout0, yv);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int cout = cout0 + c;
-                float x = v[c];
+                float x = acc[i][j][c];
                 if (cout < p.Cout) {
                     if (p.scale) x *= p.scale[cout];
                     if (p.bias) x += p.bias[cout];
@@ -143,42 +154,36 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                 } else {
                     x = 0.f;
                 }
-                v[c] = x;
-                if (p.stats) {
-                    const float xr = pok ? OutVec4<OT>::round(x) : 0.f;
-                    s1[i][c] += xr;
-                    s2[i][c] += xr * xr;
-                }
+                acc[i][j][c] = x;
             }
-            if (pok) OutVec4<OT>::store(Y + yoff + cout0, v);
         }
     }
 
     if (p.stats) {
-        // reduce over the 16 pixel lanes that share (lane>>4); then over the WAVES_P waves via LDS
+        // per-channel (sum, sum^2) of the stored values: over this lane's MP pixels, then over the 16 pixel
+        // lanes that share (lane>>4) by xor-shuffles, then over the WAVES_P waves via LDS
 #pragma unroll
         for (int i = 0; i < C::MC; ++i)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float a = s1[i][c], q = s2[i][c];
+                float a = 0.f, q = 0.f;
+#pragma unroll
+                for (int j = 0; j < C::MP; ++j) {
+                    const bool pok = ((unsigned)p0 + wp * C::WTP + j * 16 + lcol) < P;
+                    const float xr = pok ? OutVec4<OT>::round(acc[i][j][c]) : 0.f;
+                    a += xr; q += xr * xr;
+                }
 #pragma unroll
                 for (int m = 1; m < 16; m <<= 1) {
                     a += __shfl_xor(a, m, 64);
                     q += __shfl_xor(q, m, 64);
                 }
-                s1[i][c] = a; s2[i][c] = q;
-            }
-        __syncthreads();     // everyone is done with the tile buffers
-        if (lcol == 0) {
-#pragma unroll
-            for (int i = 0; i < C::MC; ++i)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                if (lcol == 0) {
                     const int row = wc * C::WTC + i * 16 + lrow4 + c;      // 0..TC-1
-                    lds_f[(wp * TC + row) * 2 + 0] = s1[i][c];
-                    lds_f[(wp * TC + row) * 2 + 1] = s2[i][c];
+                    lds_f[(wp * TC + row) * 2 + 0] = a;
+                    lds_f[(wp * TC + row) * 2 + 1] = q;
                 }
-        }
+            }
         __syncthreads();
         const int t = threadIdx.x;
         if (t < TC) {
@@ -194,6 +199,39 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                 p.stats[((long)tp * p.Cout + cout) * 2 + 1] = q;
             }
         }
+        __syncthreads();
+    }
+
+    // ---- phase B: stage through LDS, store whole rows ----------------------------------------------
+    unsigned char* stage = lds + (threadIdx.x >> 6) * REGION;
+    const int sp = lane / LPP, sc = lane % LPP;                // store phase: pixel slot, 16-byte chunk
+    const int ccol = c0 + wc * C::WTC + sc * EV;               // first channel of this lane's chunk
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+        for (int jj = 0; jj < PASS_TILES; ++jj) {
+            const int j = ps * PASS_TILES + jj;
+#pragma unroll
+            for (int i = 0; i < C::MC; ++i) {
+                const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                OutVec4<OT>::store(reinterpret_cast<OT*>(stage + (jj * 16 + lcol) * SROW + (i * 16 + lrow4) * OSZ), v);
+            }
+        }
+        __syncthreads();
+        // first pixel handled by this lane in this pass, then advance PPI pixels per store
+        unsigned pix = (unsigned)p0 + wp * C::WTP + ps * PASS_TILES * 16 + sp;
+        unsigned b = (pix < P ? pix : 0u) / HoWo;
+        unsigned rem = (pix < P ? pix : 0u) - b * HoWo;
+#pragma unroll
+        for (int k = 0; k < PASS_TILES * 16 / PPI; ++k) {
+            if (pix < P && ccol < p.Cout_store) {
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(stage + (k * PPI + sp) * SROW + sc * 16);
+                *reinterpret_cast<u32x4_t*>(Y + (long)b * p.y_sB + (long)rem * p.y_sP + ccol) = v;
+            }
+            pix += PPI; rem += PPI;
+            while (rem >= HoWo) { rem -= HoWo; ++b; }
+        }
+        if (ps + 1 < NPASS) __syncthreads();
     }
 }
 
@@ -330,9 +368,8 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams 
     if (it < nsteps) compute(0);
     __syncthreads();
 
-    float* lds_f = reinterpret_cast<float*>(lds);
-    if (p.out_f32) conv_epilogue<T, float, TC, TP>(p, acc, c0, p0, wc, wp, lane, tp, lds_f);
-    else           conv_epilogue<T, T, TC, TP>(p, acc, c0, p0, wc, wp, lane, tp, lds_f);
+    if (p.out_f32) conv_epilogue<T, float, TC, TP>(p, acc, c0, p0, wc, wp, lane, tp, lds);
+    else           conv_epilogue<T, T, TC, TP>(p, acc, c0, p0, wc, wp, lane, tp, lds);
 }
 
 constexpr int kTP = 128;
@@ -365,6 +402,12 @@ extern "C" int mpn_conv_stats_tiles(const MpnConvParams* p) {
     if (!p) return MPN_E_BADARG;
     const long P = (long)p->B * p->Ho * p->Wo;
     return (int)((P + kTP - 1) / kTP);
+}
+
+extern "C" int mpn_conv_tile_rows(const MpnConvParams* p) {
+    if (!p) return MPN_E_BADARG;
+    const long P = (long)p->B * p->Ho * p->Wo;
+    return pick_tc(p->Cout_store, (P + kTP - 1) / kTP);
 }
 
 extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {

@@ -178,8 +178,7 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
     if KERNEL_EVENTS.on:
         e0 = KERNEL_EVENTS.begin()
         call("mpn_conv_forward", ctypes.byref(p), stream_ptr())
-        cs = p.Cout_store
-        tc = 128 if cs > 64 else (64 if cs > 32 else 32)
+        tc = call("mpn_conv_tile_rows", ctypes.byref(p))
         # algorithmic FLOPs: 2 * output pixels * Cout * taps * Cin; a stride-s dgrad only has 1/s^2 live taps
         live = (R * S) / float(stride * stride) if mode == 1 else R * S
         flops = 2.0 * x.B * Ho * Wo * Cout * live * min(Cin, x.C if x_geom is None else Cin)
