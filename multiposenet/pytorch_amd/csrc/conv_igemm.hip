@@ -21,6 +21,7 @@
 // dgrad reuses the kernel with mode=1 (transposed gather hi = (ho + pad - r)/stride) and the
 // [Cin][R][S][Cout_pad] weight copy made by mpn_weight_transpose.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -91,9 +92,24 @@ struct ConvCfg {
 // accumulate, activation, BN partial sums.  Phase B: the finished tile goes through a per-wave LDS staging
 // area and leaves as 16-byte stores with 8..16 lanes covering one pixel's contiguous channels (full 128-byte
 // lines per wave-instruction) instead of 16 strided 8-byte stores per lane.
-template <typename T, typename OT, int TC, int TP>
+// sum over the 16 lanes of a DPP row (lanes sharing lane>>4); every lane ends with the total.
+// quad_perm xor-1 / xor-2 butterflies, then row_half_mirror and row_mirror (cdna4 DPP controls).
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+
+// Epilogue.  Phase A (accumulator layout: lane = 4 consecutive couts of one pixel): scale, bias, residual,
+// accumulate, activation — branch-free per element (uniform conditions only); skipped entirely for the plain
+// conv+BN-stats case.  BN partial sums use DPP row reductions.  Phase B: the finished tile goes through a
+// per-wave LDS staging area and leaves as 16-byte stores with 8..16 lanes covering one pixel's contiguous
+// channels (full 128-byte lines per wave-instruction).
+template <typename T, typename OT, int TC, int TP, bool GENERAL>
 __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&acc)[ConvCfg<T, TC, TP>::MC][ConvCfg<T, TC, TP>::MP],
-                                              int c0, long p0, int wc, int wp, int lane, int tp, unsigned char* lds) {
+                                              int c0, long p0, int wc, int wp, int lane, int tp, unsigned char* lds, const int dbg) {
     using C = ConvCfg<T, TC, TP>;
     constexpr int OSZ = (int)sizeof(OT);
     constexpr int PASS_TILES = (OSZ == 4) ? ((C::MP >= 2) ? C::MP / 2 : 1) : C::MP;   // pixel tiles staged per pass
@@ -112,56 +128,54 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
     const int lcol = lane & 15;
     float* lds_f = reinterpret_cast<float*>(lds);
 
-    // ---- phase A: finish the values in registers -------------------------------------------------
-    const bool simple = (p.res_mode == 0) && !p.accumulate;
-#pragma unroll
-    for (int j = 0; j < C::MP; ++j) {
-        const unsigned pix = (unsigned)p0 + wp * C::WTP + j * 16 + lcol;
-        const bool pok = pix < P;
-        long yoff = 0, roff = 0;
-        if (!simple) {
-            const unsigned pc = pok ? pix : 0u;
-            const unsigned b = pc / HoWo;
-            const unsigned rem = pc - b * HoWo;
-            yoff = (long)b * p.y_sB + (long)rem * p.y_sP;
-            if (p.res_mode == 1) {
-                roff = (long)b * p.res_sB + (long)rem * p.res_sP;
-            } else if (p.res_mode == 2) {
-                const unsigned ho = rem / (unsigned)p.Wo, wo = rem - ho * (unsigned)p.Wo;
-                const unsigned rh = (ho * (unsigned)p.res_H) / (unsigned)p.Ho, rw = (wo * (unsigned)p.res_W) / (unsigned)p.Wo;
-                roff = (long)b * p.res_sB + (long)(rh * (unsigned)p.res_W + rw) * p.res_sP;
-            }
-        }
+    // ---- phase A (general kernels only): per-channel scale / bias / activation in registers ----------
+    if (GENERAL) {
+        const float relu_lo = (p.act == 1) ? 0.f : -INFINITY;
 #pragma unroll
         for (int i = 0; i < C::MC; ++i) {
             const int cout0 = c0 + wc * C::WTC + i * 16 + lrow4;
-            float rv[4] = {0.f, 0.f, 0.f, 0.f};
-            float yv[4] = {0.f, 0.f, 0.f, 0.f};
-            const bool live = pok && cout0 < p.Cout_store;
-            if (live && p.res_mode != 0) OutVec4<OT>::load(Rz + roff + cout0, rv);
-            if (live && p.accumulate) OutVec4<OT>::load(Y + yoff + cout0, yv);
+            float sc[4] = {1.f, 1.f, 1.f, 1.f}, bs[4] = {0.f, 0.f, 0.f, 0.f}, lm[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int cout = cout0 + c;
-                float x = acc[i][j][c];
-                if (cout < p.Cout) {
-                    if (p.scale) x *= p.scale[cout];
-                    if (p.bias) x += p.bias[cout];
-                    x += rv[c];
-                    x += yv[c];
-                    if (p.act == 1) x = fmaxf(x, 0.f);
-                    else if (p.act == 2) x = 1.0f / (1.0f + expf(-x));
-                } else {
-                    x = 0.f;
+            for (int c = 0; c < 4; ++c) lm[c] = (cout0 + c) < p.Cout ? 1.f : 0.f;
+            if (cout0 + 4 <= p.Cout) {                                   // whole group in range: one float4 per array
+                if (p.scale) { const float4 t = *reinterpret_cast<const float4*>(p.scale + cout0); sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w; }
+                if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + cout0); bs[0] = t.x; bs[1] = t.y; bs[2] = t.z; bs[3] = t.w; }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int ci = (cout0 + c) < p.Cout ? cout0 + c : p.Cout - 1;
+                    if (p.scale) sc[c] = p.scale[ci];
+                    if (p.bias) bs[c] = p.bias[ci];
                 }
-                acc[i][j][c] = x;
             }
+#pragma unroll
+            for (int j = 0; j < C::MP; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float x = acc[i][j][c] * sc[c] + bs[c];
+                    x = fmaxf(x, relu_lo);
+                    acc[i][j][c] = x * lm[c];
+                }
+        }
+        if (p.act == 2) {
+#pragma unroll
+            for (int i = 0; i < C::MC; ++i)
+#pragma unroll
+                for (int j = 0; j < C::MP; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float lv = (c0 + wc * C::WTC + i * 16 + lrow4 + c) < p.Cout ? 1.f : 0.f;
+                        acc[i][j][c] = lv / (1.0f + expf(-acc[i][j][c]));
+                    }
         }
     }
 
-    if (p.stats) {
+    if (p.stats && !(dbg & 64)) {
         // per-channel (sum, sum^2) of the stored values: over this lane's MP pixels, then over the 16 pixel
-        // lanes that share (lane>>4) by xor-shuffles, then over the WAVES_P waves via LDS
+        // lanes of the DPP row, then over the WAVES_P waves via LDS
+        float pm[C::MP];
+#pragma unroll
+        for (int j = 0; j < C::MP; ++j) pm[j] = (((unsigned)p0 + wp * C::WTP + j * 16 + lcol) < P) ? 1.f : 0.f;
 #pragma unroll
         for (int i = 0; i < C::MC; ++i)
 #pragma unroll
@@ -169,19 +183,14 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                 float a = 0.f, q = 0.f;
 #pragma unroll
                 for (int j = 0; j < C::MP; ++j) {
-                    const bool pok = ((unsigned)p0 + wp * C::WTP + j * 16 + lcol) < P;
-                    const float xr = pok ? OutVec4<OT>::round(acc[i][j][c]) : 0.f;
+                    const float xr = OutVec4<OT>::round(acc[i][j][c]) * pm[j];
                     a += xr; q += xr * xr;
                 }
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) {
-                    a += __shfl_xor(a, m, 64);
-                    q += __shfl_xor(q, m, 64);
-                }
+                a = row16_sum(a);
+                q = row16_sum(q);
                 if (lcol == 0) {
                     const int row = wc * C::WTC + i * 16 + lrow4 + c;      // 0..TC-1
-                    lds_f[(wp * TC + row) * 2 + 0] = a;
-                    lds_f[(wp * TC + row) * 2 + 1] = q;
+                    *reinterpret_cast<float2*>(lds_f + (wp * TC + row) * 2) = make_float2(a, q);
                 }
             }
         __syncthreads();
@@ -195,17 +204,17 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                     a += lds_f[(w * TC + t) * 2 + 0];
                     q += lds_f[(w * TC + t) * 2 + 1];
                 }
-                p.stats[((long)tp * p.Cout + cout) * 2 + 0] = a;
-                p.stats[((long)tp * p.Cout + cout) * 2 + 1] = q;
+                *reinterpret_cast<float2*>(p.stats + ((long)tp * p.Cout + cout) * 2) = make_float2(a, q);
             }
         }
         __syncthreads();
     }
 
     // ---- phase B: stage through LDS, store whole rows ----------------------------------------------
+    if (dbg & 256) { if (acc[0][0][0] == 123.456f) ((float*)p.y)[0] = 1.f; return; }
     unsigned char* stage = lds + (threadIdx.x >> 6) * REGION;
-    const int sp = lane / LPP, sc = lane % LPP;                // store phase: pixel slot, 16-byte chunk
-    const int ccol = c0 + wc * C::WTC + sc * EV;               // first channel of this lane's chunk
+    const int sp = lane / LPP, sc_ = lane % LPP;               // store phase: pixel slot, 16-byte chunk
+    const int ccol = c0 + wc * C::WTC + sc_ * EV;              // first channel of this lane's chunk
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
@@ -224,9 +233,33 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
         unsigned rem = (pix < P ? pix : 0u) - b * HoWo;
 #pragma unroll
         for (int k = 0; k < PASS_TILES * 16 / PPI; ++k) {
-            if (pix < P && ccol < p.Cout_store) {
-                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(stage + (k * PPI + sp) * SROW + sc * 16);
-                *reinterpret_cast<u32x4_t*>(Y + (long)b * p.y_sB + (long)rem * p.y_sP + ccol) = v;
+            if (pix < P && ccol < p.Cout_store && !(dbg & 128)) {
+                u32x4_t v = *reinterpret_cast<const u32x4_t*>(stage + (k * PPI + sp) * SROW + sc_ * 16);
+                OT* dst = Y + (long)b * p.y_sB + (long)rem * p.y_sP + ccol;
+                if (GENERAL && (p.res_mode != 0 || p.accumulate)) {
+                    // residual (same-size or nearest-upsampled source) and accumulate: 16-byte coalesced loads
+                    Vec16<OT> a; a.load(reinterpret_cast<const OT*>(&v));
+                    if (p.res_mode != 0) {
+                        long ro;
+                        if (p.res_mode == 1) {
+                            ro = (long)b * p.res_sB + (long)rem * p.res_sP;
+                        } else {
+                            const unsigned ho = rem / (unsigned)p.Wo, wo = rem - ho * (unsigned)p.Wo;
+                            const unsigned rh = (ho * (unsigned)p.res_H) / (unsigned)p.Ho, rw = (wo * (unsigned)p.res_W) / (unsigned)p.Wo;
+                            ro = (long)b * p.res_sB + (long)(rh * (unsigned)p.res_W + rw) * p.res_sP;
+                        }
+                        Vec16<OT> r; r.load(Rz + ro + ccol);
+#pragma unroll
+                        for (int e = 0; e < EV; ++e) a.v[e] += r.v[e];
+                    }
+                    if (p.accumulate) {
+                        Vec16<OT> r; r.load(dst);
+#pragma unroll
+                        for (int e = 0; e < EV; ++e) a.v[e] += r.v[e];
+                    }
+                    a.store(reinterpret_cast<OT*>(&v));
+                }
+                *reinterpret_cast<u32x4_t*>(dst) = v;
             }
             pix += PPI; rem += PPI;
             while (rem >= HoWo) { rem -= HoWo; ++b; }
@@ -235,8 +268,8 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
     }
 }
 
-template <typename T, int TC, int TP>
-__global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams p) {
+template <typename T, int TC, int TP, bool OUTF32, bool GENERAL>
+__global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams p, const int dbg) {
     using C = ConvCfg<T, TC, TP>;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * C::BUF_BYTES];
 
@@ -349,6 +382,7 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams 
 #pragma unroll
             for (int j = 0; j < C::MP; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
     };
+    if (dbg & 32) return;                    // ablation: prologue only
 
     gload(ra0, rb0);
     if (nsteps > 1) gload(ra1, rb1);
@@ -368,8 +402,9 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams 
     if (it < nsteps) compute(0);
     __syncthreads();
 
-    if (p.out_f32) conv_epilogue<T, float, TC, TP>(p, acc, c0, p0, wc, wp, lane, tp, lds);
-    else           conv_epilogue<T, T, TC, TP>(p, acc, c0, p0, wc, wp, lane, tp, lds);
+    if (dbg & 16) { if (acc[0][0][0] == 123.456f) ((float*)p.y)[0] = 1.f; return; }   // ablation: no epilogue
+    if (OUTF32) conv_epilogue<T, float, TC, TP, GENERAL>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg);
+    else        conv_epilogue<T, T, TC, TP, GENERAL>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg);
 }
 
 constexpr int kTP = 128;
@@ -382,7 +417,15 @@ inline int pick_tc(int cout_store, long tilesP) {
     return blocks128 >= 768 ? 128 : 64;
 }
 
-template <typename T>
+template <typename T, bool OUTF32, bool GENERAL>
+int launch_conv_k(const MpnConvParams& p, int tc, long grid, int dbg, hipStream_t st) {
+    if (tc == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+    else if (tc == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+    else hipLaunchKernelGGL((conv_igemm_kernel<T, 32, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+    return mpn_launch_status();
+}
+
+template <typename T, bool OUTF32>
 int launch_conv(const MpnConvParams& p, hipStream_t st) {
     const long P = (long)p.B * p.Ho * p.Wo;
     const long tilesP = (P + kTP - 1) / kTP;
@@ -390,10 +433,10 @@ int launch_conv(const MpnConvParams& p, hipStream_t st) {
     const long tilesC = (p.Cout_store + tc - 1) / tc;
     const long grid = tilesP * tilesC;
     if (grid <= 0 || grid > 0x7fffffffL || P >= 0x7fffffffL) return MPN_E_BADARG;
-    if (tc == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, kTP>), dim3((unsigned)grid), dim3(256), 0, st, p);
-    else if (tc == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, kTP>), dim3((unsigned)grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_igemm_kernel<T, 32, kTP>), dim3((unsigned)grid), dim3(256), 0, st, p);
-    return mpn_launch_status();
+    static const int dbg = getenv("MPN_DEBUG_FLAGS") ? atoi(getenv("MPN_DEBUG_FLAGS")) : 0;   // microbenchmark ablations only
+    // "plain" = conv (+ BN tile statistics): no per-element epilogue math at all, lighter register footprint
+    const bool general = p.scale || p.bias || p.res_mode || p.accumulate || p.act || (p.Cout % tc) != 0;
+    return general ? launch_conv_k<T, OUTF32, true>(p, tc, grid, dbg, st) : launch_conv_k<T, OUTF32, false>(p, tc, grid, dbg, st);
 }
 
 }  // namespace
@@ -424,7 +467,8 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     MPN_CHECK_ARG(!(p.accumulate && p.act != 0));
     MPN_CHECK_ARG(p.res_mode == 0 || p.res != nullptr);
     MPN_CHECK_ARG(!(p.stats && (p.bias || p.scale || p.res_mode || p.accumulate || p.act)));
+    MPN_CHECK_ARG(!((p.res_mode || p.accumulate) && p.act));          // activation is applied before the residual stage
     hipStream_t st = (hipStream_t)stream;
-    if (p.dtype == MPN_F32) return launch_conv<float>(p, st);
-    return launch_conv<bf16_t>(p, st);
+    if (p.dtype == MPN_F32) return launch_conv<float, false>(p, st);       // OT == T == float
+    return p.out_f32 ? launch_conv<bf16_t, true>(p, st) : launch_conv<bf16_t, false>(p, st);
 }

@@ -347,8 +347,8 @@ extern "C" int mpn_conv_wgrad_chunks(const MpnWgradParams* p) {
     const int tm = pick_tile(p->Cin), tn = pick_tile(p->Cout);
     const long tiles = (long)((p->Cin + tm - 1) / tm) * ((p->Cout + tn - 1) / tn) * p->R * p->S;
     const long P = (long)p->B * p->Ho * p->Wo;
-    long want = (768 + tiles - 1) / tiles;            // ~3 workgroups per CU in flight
-    const long maxc = P / 1024 > 0 ? P / 1024 : 1;    // >= 1024 pixels (32 k-steps) per slice: each slice costs a TMxTN f32 partial round trip
+    long want = (1536 + tiles - 1) / tiles;           // ~6 workgroups per CU queued (measured better than 3: latency-bound slices)
+    const long maxc = (P + 511) / 512;                 // keep >= 512 pixels per slice
     if (want > maxc) want = maxc;
     if (want < 1) want = 1;
     if (want > 256) want = 256;

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the conv kernels on the shapes that dominate the R101 480x480 B=32 step.
+Run on the GPU box: python tools/conv_microbench.py [MPN_DEBUG_FLAGS via env]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from multiposenet.pytorch_amd import ops
+
+SHAPES_ALL = [
+    # name, B, H, W, Cin, Cout, k, stride, pad, stats
+    ("1x1 64->256 @120 stats", 32, 120, 120, 64, 256, 1, 1, 0, True),
+    ("1x1 256->64 @120 stats", 32, 120, 120, 256, 64, 1, 1, 0, True),
+    ("1x1 256->1024 @30 stats", 32, 30, 30, 256, 1024, 1, 1, 0, True),
+    ("1x1 1024->256 @30 stats", 32, 30, 30, 1024, 256, 1, 1, 0, True),
+    ("3x3 256->256 @30 stats", 32, 30, 30, 256, 256, 3, 1, 1, True),
+    ("3x3 256->256 @60 bias", 32, 60, 60, 256, 256, 3, 1, 1, False),
+    ("3x3 512->256 @120 bias", 32, 120, 120, 512, 256, 3, 1, 1, False),
+    ("3x3 64->64 @120 stats", 32, 120, 120, 64, 64, 3, 1, 1, True),
+]
+
+
+SHAPES = SHAPES_ALL if os.environ.get('MB_ALL', '1') == '1' else SHAPES_ALL[:3]
+WGRAD = os.environ.get('MB_WGRAD', '1') == '1'
+
+
+def main():
+    dt = torch.bfloat16
+    dev = "cuda"
+    for name, B, H, W, Cin, Cout, k, stride, pad, stats in SHAPES:
+        x = ops.Act(torch.randn(B, H, W, Cin, device=dev).to(dt), Cin)
+        w = (torch.randn(Cout, k, k, Cin, device=dev) / (Cin * k * k) ** 0.5).to(dt)
+        bias = None if stats else torch.randn(Cout, device=dev)
+        out = ops.Act.empty(B, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1, Cout, dt, dev)
+        for _ in range(3):
+            ops.conv_forward(x, w, Cout, k, k, stride, pad, bias=bias, want_stats=stats, out=out)
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        n = 20
+        e0.record()
+        for _ in range(n):
+            ops.conv_forward(x, w, Cout, k, k, stride, pad, bias=bias, want_stats=stats, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1000 / n
+        flops = 2.0 * out.P * Cout * k * k * Cin
+        byts = (x.t.numel() + out.t.numel() + w.numel()) * 2
+        print("%-28s %9.1f us  %7.1f TF/s  %7.1f GB/s(alg)" % (name, us, flops / us / 1e6, byts / us / 1e3), flush=True)
+        if not WGRAD:
+            continue
+        # wgrad of the same layer
+        dy = ops.Act(torch.randn(out.t.shape, device=dev).to(dt), Cout)
+        dw = torch.zeros(Cout, k, k, Cin, device=dev)
+        for _ in range(2):
+            ops.conv_wgrad(x, dy, dw, Cout, k, k, stride, pad)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            ops.conv_wgrad(x, dy, dw, Cout, k, k, stride, pad)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1000 / n
+        print("%-28s %9.1f us  %7.1f TF/s   (wgrad + reduce)" % ("", us, flops / us / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    print("MPN_DEBUG_FLAGS =", os.environ.get("MPN_DEBUG_FLAGS", "0"))
+    main()
