@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-baseline-worker", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and the gradient reducer even with one rank")
     return ap.parse_args()
 
 
@@ -153,15 +154,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         dist = None
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local if world > 1 else 0)
+    dev = torch.device("cuda", local if use_dist else 0)
 
     from multiposenet.pytorch_amd import ddp, ops
     from multiposenet.pytorch_amd.network.posenet import poseNet
@@ -173,7 +178,7 @@ def main():
     for p in model.prn.parameters():          # PRN is not part of this step (all non-PRN params trainable)
         p.requires_grad = False
     model.train()
-    if world > 1:
+    if use_dist:
         ddp.attach(model, bucket_mb=32.0)
     opt = FusedAdam(model, lr=1e-4, weight_decay=0.0)
     img, heat, wgt, anno = synth(args.batch, args.size, dev, seed=100 + rank)

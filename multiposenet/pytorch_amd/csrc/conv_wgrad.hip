@@ -69,7 +69,8 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(const MpnWgradParams
     const int wm = wave >> 1, wn = wave & 1;
     const int tilesM = (p.Cin + TM - 1) / TM, tilesN = (p.Cout + TN - 1) / TN;
     const int taps = p.R * p.S;
-    int bid = blockIdx.x;
+    // XCD-aware order: the tile-blocks of one pixel slice (which re-read the same X / dY rows) share an L2
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = bid % tilesN; bid /= tilesN;
     const int tm = bid % tilesM; bid /= tilesM;
     const int tap = bid % taps; bid /= taps;
