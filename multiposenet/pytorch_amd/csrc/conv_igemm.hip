@@ -282,24 +282,29 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams 
     const int tp = bid / tilesC, tc = bid - tp * tilesC;
     const long p0 = (long)tp * TP;
     const int c0 = tc * TC;
-    const T* __restrict__ X = (const T*)p.x;
-    const T* __restrict__ Wg = (const T*)p.w;
+    constexpr unsigned TS = (unsigned)sizeof(T);
     const long KW = (long)p.R * p.S * p.Cin;
     const int sh = p.stride - 1;          // dgrad supports stride 1 or 2
+    // Operands are read through buffer descriptors: 32-bit per-lane byte offsets, the k-chunk offset rides in
+    // the scalar soffset, and an out-of-range offset returns 0 — halo pixels and rows beyond Cout need no
+    // branch, no select and no 64-bit address arithmetic (launcher guarantees both tensors are < 4 GB).
+    const unsigned x_bytes = (unsigned)((long)p.B * p.x_sB * TS);
+    const unsigned w_bytes = (unsigned)((long)p.Cout * KW * TS);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, w_bytes, 0x00020000);
 
-    long a_off[C::A_PER_T];
-    bool a_ok[C::A_PER_T];
+    unsigned a_voff[C::A_PER_T];
     int a_lds[C::A_PER_T];
 #pragma unroll
     for (int q = 0; q < C::A_PER_T; ++q) {
         const int u = tid + 256 * q;
         const int row = u >> 2, ch = u & 3;
         const int cout = c0 + row;
-        a_ok[q] = (u < TC * 4) && (cout < p.Cout);
-        a_off[q] = (long)cout * KW + ch * C::V;
+        const bool ok = (u < TC * 4) && (cout < p.Cout);
+        a_voff[q] = ok ? (unsigned)(((long)cout * KW + ch * C::V) * TS) : w_bytes;
         a_lds[q] = (u < TC * 4) ? row * LDS_ROW + ch * 16 : -1;
     }
-    long b_base[C::B_PER_T];
+    unsigned b_base[C::B_PER_T], b_voff[C::B_PER_T];
     int b_h[C::B_PER_T], b_w[C::B_PER_T];
     bool b_ok[C::B_PER_T];
     int b_lds[C::B_PER_T];
@@ -316,9 +321,11 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams 
         b_ok[q] = ok;
         if (p.mode == 0) { b_h[q] = ho * p.stride - p.pad; b_w[q] = wo * p.stride - p.pad; }
         else             { b_h[q] = ho + p.pad;            b_w[q] = wo + p.pad; }
-        b_base[q] = (long)b * p.x_sB + ch * C::V;
+        b_base[q] = (unsigned)(((long)b * p.x_sB + ch * C::V) * TS);
+        b_voff[q] = x_bytes;
         b_lds[q] = (u < TP * 4) ? (TC + row) * LDS_ROW + ch * 16 : -1;
     }
+    const unsigned sH_b = (unsigned)(p.x_sH * TS), sW_b = (unsigned)(p.x_sW * TS);
 
     f32x4_t acc[C::MC][C::MP];
 #pragma unroll
@@ -328,31 +335,35 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams 
 
     const int nsteps = p.R * p.S * (p.Cin / C::KC);
     int r = 0, s = 0, cc = 0;
-    long klin = 0;
+    int klin = 0;
     // two register stages: loads run TWO k-steps ahead of the MFMAs (global latency ~1 us per hop is the
     // critical path of a short k-step; one stage in flight while the other is written to LDS)
     u32x4_t ra0[C::A_PER_T], rb0[C::B_PER_T], ra1[C::A_PER_T], rb1[C::B_PER_T];
-    const u32x4_t zero4 = (u32x4_t){0u, 0u, 0u, 0u};
 
     auto gload = [&](u32x4_t (&ra)[C::A_PER_T], u32x4_t (&rb)[C::B_PER_T]) {
+        if (cc == 0) {                       // new tap (uniform): per-row gather offsets, OOB offset for halo / dead rows
+#pragma unroll
+            for (int q = 0; q < C::B_PER_T; ++q) {
+                int hi, wi;
+                bool ok = b_ok[q];
+                if (p.mode == 0) {
+                    hi = b_h[q] + r; wi = b_w[q] + s;
+                } else {
+                    const int th = b_h[q] - r, tw = b_w[q] - s;
+                    ok = ok && th >= 0 && tw >= 0 && (((th | tw) & sh) == 0);
+                    hi = th >> sh; wi = tw >> sh;
+                }
+                ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                b_voff[q] = ok ? b_base[q] + (unsigned)hi * sH_b + (unsigned)wi * sW_b : x_bytes;
+            }
+        }
+        const unsigned so_w = (unsigned)klin * TS, so_x = (unsigned)cc * TS;
 #pragma unroll
         for (int q = 0; q < C::A_PER_T; ++q)
-            ra[q] = a_ok[q] ? *reinterpret_cast<const u32x4_t*>(Wg + a_off[q] + klin) : zero4;
+            ra[q] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, a_voff[q], so_w, 0));
 #pragma unroll
-        for (int q = 0; q < C::B_PER_T; ++q) {
-            int hi, wi;
-            bool ok = b_ok[q];
-            if (p.mode == 0) {
-                hi = b_h[q] + r; wi = b_w[q] + s;
-            } else {
-                const int th = b_h[q] - r, tw = b_w[q] - s;
-                ok = ok && th >= 0 && tw >= 0 && (((th | tw) & sh) == 0);
-                hi = th >> sh; wi = tw >> sh;
-            }
-            ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const long off = b_base[q] + (long)hi * p.x_sH + (long)wi * p.x_sW + cc;
-            rb[q] = ok ? *reinterpret_cast<const u32x4_t*>(X + off) : zero4;
-        }
+        for (int q = 0; q < C::B_PER_T; ++q)
+            rb[q] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, b_voff[q], so_x, 0));
         // advance (tap, channel-chunk)
         klin += C::KC; cc += C::KC;
         if (cc == p.Cin) { cc = 0; if (++s == p.S) { s = 0; ++r; } }
@@ -467,7 +478,11 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     MPN_CHECK_ARG(!(p.accumulate && p.act != 0));
     MPN_CHECK_ARG(p.res_mode == 0 || p.res != nullptr);
     MPN_CHECK_ARG(!(p.stats && (p.bias || p.scale || p.res_mode || p.accumulate || p.act)));
-    MPN_CHECK_ARG(!((p.res_mode || p.accumulate) && p.act));          // activation is applied before the residual stage
+    MPN_CHECK_ARG(!((p.res_mode || p.accumulate) && p.act));
+    {   // buffer descriptors address at most 4 GB per operand
+        const int64_t ts = p.dtype == MPN_F32 ? 4 : 2;
+        if ((int64_t)p.B * p.x_sB * ts >= 0xfffffff0LL || (int64_t)p.Cout * p.R * p.S * p.Cin * ts >= 0xfffffff0LL) return MPN_E_UNSUPPORTED;
+    }          // activation is applied before the residual stage
     hipStream_t st = (hipStream_t)stream;
     if (p.dtype == MPN_F32) return launch_conv<float, false>(p, st);       // OT == T == float
     return p.out_f32 ? launch_conv<bf16_t, true>(p, st) : launch_conv<bf16_t, false>(p, st);
