@@ -336,9 +336,9 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams 
     const int nsteps = p.R * p.S * (p.Cin / C::KC);
     int r = 0, s = 0, cc = 0;
     int klin = 0;
-    // two register stages: loads run TWO k-steps ahead of the MFMAs (global latency ~1 us per hop is the
+    // three register stages: loads run THREE k-steps ahead of the MFMAs (global latency ~1 us per hop is the
     // critical path of a short k-step; one stage in flight while the other is written to LDS)
-    u32x4_t ra0[C::A_PER_T], rb0[C::B_PER_T], ra1[C::A_PER_T], rb1[C::B_PER_T];
+    u32x4_t ra0[C::A_PER_T], rb0[C::B_PER_T], ra1[C::A_PER_T], rb1[C::B_PER_T], ra2[C::A_PER_T], rb2[C::B_PER_T];
 
     auto gload = [&](u32x4_t (&ra)[C::A_PER_T], u32x4_t (&rb)[C::B_PER_T]) {
         if (cc == 0) {                       // new tap (uniform): per-row gather offsets, OOB offset for halo / dead rows
@@ -397,21 +397,28 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams 
 
     gload(ra0, rb0);
     if (nsteps > 1) gload(ra1, rb1);
+    if (nsteps > 2) gload(ra2, rb2);
     lstore(0, ra0, rb0);
     __syncthreads();
-    int it = 0;
-    for (; it + 1 < nsteps; it += 2) {
-        if (it + 2 < nsteps) gload(ra0, rb0);       // step it+2
-        compute(0);                                  // step it
-        lstore(1, ra1, rb1);                         // step it+1 (loaded one half-iteration ago)
-        __syncthreads();
-        if (it + 3 < nsteps) gload(ra1, rb1);       // step it+3
-        compute(1);                                  // step it+1
-        if (it + 2 < nsteps) lstore(0, ra0, rb0);   // step it+2
-        __syncthreads();
+    // step k: issue loads of step k+3 into the register stage that was just drained, run the MFMAs of step k
+    // from LDS buffer k%2, write step k+1's registers to the other buffer, one barrier.  Unrolled by 6 so
+    // every register stage / LDS buffer index is a compile-time constant.
+#define MPN_STEP(J, RA_LD, RB_LD, RA_ST, RB_ST)                                   \
+    if (it + (J) < nsteps) {                                                      \
+        if (it + (J) + 3 < nsteps) gload(RA_LD, RB_LD);                           \
+        compute((J) & 1);                                                         \
+        if (it + (J) + 1 < nsteps) lstore(((J) + 1) & 1, RA_ST, RB_ST);           \
+        __syncthreads();                                                          \
     }
-    if (it < nsteps) compute(0);
-    __syncthreads();
+    for (int it = 0; it < nsteps; it += 6) {
+        MPN_STEP(0, ra0, rb0, ra1, rb1)
+        MPN_STEP(1, ra1, rb1, ra2, rb2)
+        MPN_STEP(2, ra2, rb2, ra0, rb0)
+        MPN_STEP(3, ra0, rb0, ra1, rb1)
+        MPN_STEP(4, ra1, rb1, ra2, rb2)
+        MPN_STEP(5, ra2, rb2, ra0, rb0)
+    }
+#undef MPN_STEP
 
     if (dbg & 16) { if (acc[0][0][0] == 123.456f) ((float*)p.y)[0] = 1.f; return; }   // ablation: no epilogue
     if (OUTF32) conv_epilogue<T, float, TC, TP, GENERAL>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg);
