@@ -157,6 +157,8 @@ int mpn_relu_backward(const void* dz, const void* z, void* dx, int64_t n, int ac
 int mpn_add_inplace(void* dst, const void* src, int64_t n, int dtype, void* stream);
 int mpn_channel_sum(const void* dy, int dy_dtype, int64_t P, int C, int Cs, float* partial, int chunks, void* stream);
 int mpn_channel_sum_chunks(int64_t P, int Cs, int dtype);
+/* db[c] += sum over the P rows of dy[p][c] — small P, any C (Linear-layer bias gradients) */
+int mpn_colsum_rows(const void* dy, int dy_dtype, int64_t P, int C, int Cs, float* db, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses (posenet.py:367-445, losses.py:5-137)
@@ -182,8 +184,14 @@ int mpn_focal_backward(const float* cls, const float* reg, const float* anchors,
 int mpn_sigmoid_forward(const float* x, float* y, int64_t n, void* stream);   /* in place allowed */
 /* dlogit = dp * p * (1-p) */
 int mpn_sigmoid_backward(const float* dp, const float* p, float* dlogit, int64_t n, void* stream);
-/* PRN: out = softmax(a + res) rowwise (posenet.py:345-347); BCE mean (posenet.py:436-439) */
-int mpn_add_softmax_rows(const float* a, const float* res, float* out, int rows, int cols, void* stream);
+/* PRN: out = softmax(relu?(a) + res) rowwise (posenet.py:345-347); BCE mean (posenet.py:436-439) */
+int mpn_add_softmax_rows(const float* a, const float* res, float* out, int rows, int cols, int relu, void* stream);
+/* dlogit = p*(dp - sum p*dp), masked by pre_relu > 0 when pre_relu != NULL */
+int mpn_softmax_rows_backward(const float* p, const float* dp, const float* pre_relu, float* dlogit, int rows, int cols, void* stream);
+int mpn_bce_mean_backward(const float* p, const float* label, float* dp, int64_t n, const float* gscale, void* stream);
+/* nn.Dropout (posenet.py:139,341-342): y = keep(seed, i) ? x / (1 - p) : 0, counter-based (same call with the same seed
+ * applied to a gradient is the backward) */
+int mpn_dropout(const void* x, void* y, int64_t n, uint64_t seed, float p, int dtype, void* stream);
 int mpn_bce_chunks(int64_t n);
 int mpn_bce_mean_forward(const float* p, const float* label, int64_t n, float* partial, int chunks, float* out, void* stream);
 

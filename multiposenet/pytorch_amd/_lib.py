@@ -89,6 +89,7 @@ SIGNATURES = {
     "mpn_relu_backward": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "mpn_add_inplace": (_i, [_vp, _vp, _i64, _i, _vp]),
     "mpn_channel_sum": (_i, [_vp, _i, _i64, _i, _i, _vp, _i, _vp]),
+    "mpn_colsum_rows": (_i, [_vp, _i, _i64, _i, _i, _vp, _vp]),
     "mpn_channel_sum_chunks": (_i, [_i64, _i, _i]),
     "mpn_mse_chunks": (_i, [_i64]),
     "mpn_mse_heatmap_forward": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _i, _vp, _vp]),
@@ -99,7 +100,10 @@ SIGNATURES = {
     "mpn_sigmoid_forward": (_i, [_vp, _vp, _i64, _vp]),
     "mpn_gather_dets": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "mpn_sigmoid_backward": (_i, [_vp, _vp, _vp, _i64, _vp]),
-    "mpn_add_softmax_rows": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "mpn_add_softmax_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mpn_softmax_rows_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mpn_bce_mean_backward": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "mpn_dropout": (_i, [_vp, _vp, _i64, ctypes.c_uint64, _f, _i, _vp]),
     "mpn_bce_chunks": (_i, [_i64]),
     "mpn_bce_mean_forward": (_i, [_vp, _vp, _i64, _vp, _i, _vp, _vp]),
     "mpn_box_decode_clip": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),

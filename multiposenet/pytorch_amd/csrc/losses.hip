@@ -274,13 +274,14 @@ __global__ void sigmoid_fwd_kernel(const float* __restrict__ x, float* __restric
 }
 
 // ------------------------------------------------------------------------------- PRN pieces
-__global__ void add_softmax_rows_kernel(const float* __restrict__ a, const float* __restrict__ res, float* __restrict__ out, int cols) {
+__global__ void add_softmax_rows_kernel(const float* __restrict__ a, const float* __restrict__ res, float* __restrict__ out, int cols, int relu) {
     __shared__ float sh[4];
     __shared__ float bc;
     const long row = blockIdx.x;
     const float* pa = a + row * cols; const float* pr = res + row * cols; float* po = out + row * cols;
     float mx = -INFINITY;
-    for (int i = threadIdx.x; i < cols; i += 256) mx = fmaxf(mx, pa[i] + pr[i]);
+    const float lo = relu ? 0.f : -INFINITY;      // F.relu(dens2(.)) is folded in (posenet.py:343)
+    for (int i = threadIdx.x; i < cols; i += 256) mx = fmaxf(mx, fmaxf(pa[i], lo) + pr[i]);
     mx = wave_max(mx);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
     __syncthreads();
@@ -288,7 +289,7 @@ __global__ void add_softmax_rows_kernel(const float* __restrict__ a, const float
     __syncthreads();
     mx = bc;
     float s = 0.f;
-    for (int i = threadIdx.x; i < cols; i += 256) s += expf(pa[i] + pr[i] - mx);
+    for (int i = threadIdx.x; i < cols; i += 256) s += expf(fmaxf(pa[i], lo) + pr[i] - mx);
     s = wave_sum(s);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
@@ -296,7 +297,53 @@ __global__ void add_softmax_rows_kernel(const float* __restrict__ a, const float
     if (threadIdx.x == 0) bc = sh[0] + sh[1] + sh[2] + sh[3];
     __syncthreads();
     const float inv = 1.0f / bc;
-    for (int i = threadIdx.x; i < cols; i += 256) po[i] = expf(pa[i] + pr[i] - mx) * inv;
+    for (int i = threadIdx.x; i < cols; i += 256) po[i] = expf(fmaxf(pa[i], lo) + pr[i] - mx) * inv;
+}
+
+// dlogit[r][i] = p * (dp - sum_j p_j dp_j)  (softmax backward, one block per row)
+__global__ void softmax_rows_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp, const float* __restrict__ pre, float* __restrict__ dl, int cols) {
+    __shared__ float sh[4];
+    __shared__ float bc;
+    const long row = blockIdx.x;
+    const float* pp = p + row * cols; const float* pd = dp + row * cols; float* po = dl + row * cols;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < cols; i += 256) s += pp[i] * pd[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bc = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    const float dot = bc;
+    for (int i = threadIdx.x; i < cols; i += 256) {
+        const float g = pp[i] * (pd[i] - dot);
+        po[i] = (pre == nullptr || pre[row * cols + i] > 0.f) ? g : 0.f;      // relu mask of the pre-activation
+    }
+}
+
+// BCELoss(mean) backward, torch semantics: d/dp = (p - y) / max(p (1 - p), 1e-12) / N
+__global__ void bce_bwd_kernel(const float* __restrict__ p, const float* __restrict__ y, float* __restrict__ dp, long n,
+                               const float* __restrict__ gscale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gs = (gscale ? gscale[0] : 1.f) / (float)n;
+    const float pv = p[i];
+    dp[i] = gs * (pv - y[i]) / fmaxf(pv * (1.f - pv), 1e-12f);
+}
+
+// counter-based dropout: keep element i iff hash(seed, i) >= p; kept values are scaled by 1/(1-p).
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long n, unsigned long long seed, float p, float scale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long h = mix64(mix64(seed) ^ (unsigned long long)i);
+    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
+    Elem<T>::st(y + i, u >= p ? Elem<T>::ld(x + i) * scale : 0.f);
 }
 
 __global__ void bce_partial_kernel(const float* __restrict__ p, const float* __restrict__ y, long n, float* __restrict__ partial) {
@@ -386,9 +433,29 @@ extern "C" int mpn_sigmoid_forward(const float* x, float* y, int64_t n, void* st
     return mpn_launch_status();
 }
 
-extern "C" int mpn_add_softmax_rows(const float* a, const float* res, float* out, int rows, int cols, void* stream) {
+extern "C" int mpn_add_softmax_rows(const float* a, const float* res, float* out, int rows, int cols, int relu, void* stream) {
     MPN_CHECK_ARG(a && res && out && rows > 0 && cols > 0);
-    hipLaunchKernelGGL(add_softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, a, res, out, cols);
+    hipLaunchKernelGGL(add_softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, a, res, out, cols, relu);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_softmax_rows_backward(const float* p, const float* dp, const float* pre_relu, float* dlogit, int rows, int cols, void* stream) {
+    MPN_CHECK_ARG(p && dp && dlogit && rows > 0 && cols > 0);
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, p, dp, pre_relu, dlogit, cols);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_bce_mean_backward(const float* p, const float* label, float* dp, int64_t n, const float* gscale, void* stream) {
+    MPN_CHECK_ARG(p && label && dp && n > 0);
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, label, dp, (long)n, gscale);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_dropout(const void* x, void* y, int64_t n, uint64_t seed, float p, int dtype, void* stream) {
+    MPN_CHECK_ARG(x && y && n > 0 && p >= 0.f && p < 1.f);
+    const float scale = 1.0f / (1.0f - p);
+    if (dtype == MPN_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, (long)n, (unsigned long long)seed, p, scale);
+    else hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (long)n, (unsigned long long)seed, p, scale);
     return mpn_launch_status();
 }
 

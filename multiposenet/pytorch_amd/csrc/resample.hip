@@ -279,6 +279,16 @@ __global__ void __launch_bounds__(256) channel_sum_kernel(const T* __restrict__ 
     }
 }
 
+// few rows, any channel count (bias gradient of the PRN's Linear layers): one thread per channel
+template <typename T>
+__global__ void colsum_rows_kernel(const T* __restrict__ dy, long P, int C, int Cs, float* __restrict__ db) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (long p = 0; p < P; ++p) s += Elem<T>::ld(dy + p * Cs + c);
+    db[c] += s;
+}
+
 inline int cs_lanes(int Cs, int V) { const int G = Cs / V; return 256 / (G < 256 ? G : 256); }
 inline int cs_chunk(long P, int lanes) {
     long c = P / 512;
@@ -408,6 +418,13 @@ extern "C" int mpn_add_inplace(void* dst, const void* src, int64_t n, int dtype,
     const long nvec = n / V;
     if (dtype == MPN_F32) hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(nb(nvec)), dim3(256), 0, (hipStream_t)stream, (float*)dst, (const float*)src, nvec);
     else hipLaunchKernelGGL(add_inplace_kernel<bf16_t>, dim3(nb(nvec)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dst, (const bf16_t*)src, nvec);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_colsum_rows(const void* dy, int dy_dtype, int64_t P, int C, int Cs, float* db, void* stream) {
+    MPN_CHECK_ARG(dy && db && P > 0 && C > 0 && Cs >= C);
+    if (dy_dtype == MPN_F32) hipLaunchKernelGGL(colsum_rows_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (long)P, C, Cs, db);
+    else hipLaunchKernelGGL(colsum_rows_kernel<bf16_t>, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (long)P, C, Cs, db);
     return mpn_launch_status();
 }
 

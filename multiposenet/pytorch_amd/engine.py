@@ -53,9 +53,18 @@ class Ctx(object):
         return self.grads.pop(id(act), None)
 
 
+def _geom(layer):
+    """(Cout, Cin, R, S, stride, pad) of an nn.Conv2d, or of an nn.Linear seen as a 1x1 conv on a 1x1 image."""
+    w = layer.weight
+    if w.dim() == 2:
+        return w.shape[0], w.shape[1], 1, 1, 1, 0
+    return w.shape[0], w.shape[1], w.shape[2], w.shape[3], layer.stride[0], layer.padding[0]
+
+
 class Engine(object):
     def __init__(self, model):
         self.m = model
+        self._drop_calls = 0
 
     # ------------------------------------------------------------------ weights
     @property
@@ -74,7 +83,7 @@ class Engine(object):
         key = id(layer.weight)
         wt = ctx.wt.get(key)
         if wt is None:
-            O, I, R, S = layer.weight.shape
+            O, I, R, S, _, _ = _geom(layer)
             kc = 32 if self.cdt == torch.bfloat16 else 16
             opad = round_up(O, kc)
             wt = torch.empty((I, R, S, opad), dtype=self.cdt, device=layer.weight.device)
@@ -94,8 +103,7 @@ class Engine(object):
 
     # ------------------------------------------------------------------ ops
     def conv(self, ctx, x, layer, act=0, res=None, res_mode=0, stats=False, out_f32=False, tag=""):
-        O, I, R, S = layer.weight.shape
-        stride, pad = layer.stride[0], layer.padding[0]
+        O, I, R, S, stride, pad = _geom(layer)
         bias = layer.bias
         y, st = ops.conv_forward(x, self.w_fwd(layer), O, R, S, stride, pad, bias=bias.data if bias is not None else None,
                                  act=act, res=res, res_mode=res_mode, want_stats=stats, out_f32=out_f32, tag=tag)
@@ -112,8 +120,7 @@ class Engine(object):
 
     def _conv_bwd(self, ctx, x, layer, y, act, res, res_mode):
         dy = ctx.pop_grad(y)
-        O, I, R, S = layer.weight.shape
-        stride, pad = layer.stride[0], layer.padding[0]
+        O, I, R, S, stride, pad = _geom(layer)
         bias = layer.bias
         if dy is None:       # nothing flowed back through this output (e.g. unused head)
             if layer.weight.requires_grad:
@@ -189,6 +196,25 @@ class Engine(object):
             self._grad_done(ctx, layer.bias)
         if want_dy:
             ctx.set_grad(y, dy)
+
+    def dropout(self, ctx, x, p):
+        """nn.Dropout in training mode (posenet.py:139,341-342): counter-based mask, regenerated in backward."""
+        self._drop_calls += 1
+        seed = (torch.initial_seed() * 1000003 + self._drop_calls) & 0xFFFFFFFFFFFFFFFF
+        y = Act(torch.empty_like(x.t), x.C)
+        call("mpn_dropout", ops.ptr(x.t), ops.ptr(y.t), x.t.numel(), seed, float(p), ops.dtype_code(x.t.dtype), ops.stream_ptr())
+        if ctx.train and x.needs_grad:
+            y.needs_grad = True
+
+            def bwd():
+                dy = ctx.pop_grad(y)
+                if dy is None:
+                    return
+                g = Act(torch.empty_like(dy.t), x.C)
+                call("mpn_dropout", ops.ptr(dy.t), ops.ptr(g.t), dy.t.numel(), seed, float(p), ops.dtype_code(dy.t.dtype), ops.stream_ptr())
+                ctx.set_grad(x, g)
+            ctx.tape.append(bwd)
+        return y
 
     def relu(self, ctx, x):
         z = ops.relu_forward(x)

@@ -291,7 +291,17 @@ class poseNet(nn.Module):
             return self.prn_forward(img_batch)
         elif subnet_name == 'train_both':
             return self.train_both_forward(img_batch)
-        # entire net (posenet.py:236-285): inference
+        # entire net (posenet.py:236-285): inference; detections for image 0 only, exactly like the reference
+        predict_keypoint, dets = self._entire_net(img_batch, all_images=False)
+        return predict_keypoint, dets[0]
+
+    def forward_all_images(self, img_batch):
+        """Entire-net inference with detections for EVERY image of the batch (the reference thresholds and
+        NMSes image 0 only, posenet.py:271,281).  Returns (heat-maps [B,18,H/4,W/4], [per-image
+        [nms_scores, nms_class, boxes]]); entry b equals what the reference returns for image b run alone."""
+        return self._entire_net(img_batch, all_images=True)
+
+    def _entire_net(self, img_batch, all_images):
         self._prepare(img_batch)
         eng = self._engine
         ctx = Ctx(False)
@@ -303,14 +313,18 @@ class poseNet(nn.Module):
         self._finish_forward(ctx)
         anchors = self.anchors(img_batch)
         transformed_anchors = decode_and_clip(anchors, regression, img_batch)
-        # posenet.py:269-275: threshold on image 0 only
-        dets, _src = ops.score_filter(transformed_anchors[0], classification[0, :, 0], 0.05)
-        if dets.shape[0] == 0:
-            return predict_keypoint, [torch.zeros(0), torch.zeros(0), torch.zeros(0, 4)]
-        anchors_nms_idx = nms(dets, 0.5)
-        boxes, nms_scores = ops.gather_dets(dets, anchors_nms_idx)
-        nms_class = torch.zeros(nms_scores.shape[0], dtype=torch.int64, device=nms_scores.device)   # single class
-        return predict_keypoint, [nms_scores, nms_class, boxes]
+        results = []
+        for b in range(img_batch.shape[0] if all_images else 1):
+            # posenet.py:269-275: score > 0.05, early-out with the CPU empty triple
+            dets, _src = ops.score_filter(transformed_anchors[b], classification[b, :, 0], 0.05)
+            if dets.shape[0] == 0:
+                results.append([torch.zeros(0), torch.zeros(0), torch.zeros(0, 4)])
+                continue
+            anchors_nms_idx = nms(dets, 0.5)
+            boxes, nms_scores = ops.gather_dets(dets, anchors_nms_idx)
+            nms_class = torch.zeros(nms_scores.shape[0], dtype=torch.int64, device=nms_scores.device)   # single class
+            results.append([nms_scores, nms_class, boxes])
+        return predict_keypoint, results
 
     def keypoint_forward(self, img_batch):
         """posenet.py:288-318 -> (pred [B,18,H/4,W/4], [k2,k3,k4,k5 ([B,19,...]), pred])."""
@@ -362,36 +376,51 @@ class poseNet(nn.Module):
         return [[ops.export_f32(a, a.C, a.H, a.W) for a in kp], [ops.export_f32(a, a.C, a.H, a.W) for a in det]]
 
     def prn_forward(self, img_batch):
-        """posenet.py:337-350: flatten -> fc/relu x3 -> + residual -> softmax over all 34272 -> [B,h,w,17]."""
-        if self.prn.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.prn.parameters()):
-            raise MpnError("PRN training (dropout + backward) is not built yet; run the PRN in eval mode / no_grad")
+        """posenet.py:337-350: flatten -> relu(fc) -> drop -> relu(fc) -> drop -> relu(fc) + residual -> softmax over
+        all 34272 entries -> [B, h, w, 17].  The three Linear layers run on the conv kernels (1x1 image)."""
         x = img_batch
         if not x.is_cuda:
             raise MpnError("poseNet runs on the MI355X only; there is no CPU path")
         self._prepare(x)
         eng = self._engine
+        prn = self.prn
         B = x.shape[0]
-        n = self.prn.height * self.prn.width * 17
+        n = prn.height * prn.width * 17
         res = x.detach().float().reshape(B, n).contiguous()
         if self.compute_dtype == torch.bfloat16:
             xin = torch.empty((B, 1, 1, n), dtype=torch.bfloat16, device=x.device)
             ops.cast_bf16(res, xin)
         else:
             xin = res.view(B, 1, 1, n)
-        ar = self._arena
-
-        def lin(a, L, out_f32=False):
-            w = ar.data_seg(L.weight) if self.compute_dtype == torch.float32 else ar.data_seg(L.weight, ar.bf16)
-            y, _ = ops.conv_forward(a, w, L.out_features, 1, 1, 1, 0, bias=L.bias.data, act=1, out_f32=out_f32, cin=L.in_features)
-            return y
-
-        h = lin(ops.Act(xin, n), self.prn.dens1)
-        h = lin(h, self.prn.bneck)
-        o = lin(h, self.prn.dens2, out_f32=True)
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in prn.parameters())
+        ctx = Ctx(train)
+        h, _ = eng.conv(ctx, ops.Act(xin, n), prn.dens1, act=1)
+        if prn.drop.training:
+            h = eng.dropout(ctx, h, prn.drop.p)
+        h, _ = eng.conv(ctx, h, prn.bneck, act=1)
+        if prn.drop.training:
+            h = eng.dropout(ctx, h, prn.drop.p)
+        o, _ = eng.conv(ctx, h, prn.dens2, out_f32=True)            # its ReLU is folded into the softmax kernel
         out = torch.empty((B, n), dtype=torch.float32, device=x.device)
-        call("mpn_add_softmax_rows", ops.ptr(o.t), ops.ptr(res), ops.ptr(out), B, n, ops.stream_ptr())
-        out = out.view(B, self.prn.height, self.prn.width, 17)
-        return out, [out]
+        call("mpn_add_softmax_rows", ops.ptr(o.t), ops.ptr(res), ops.ptr(out), B, n, 1, ops.stream_ptr())
+        if ctx.train and o.needs_grad:
+            def bwd():
+                g = ctx.out_grads.get("prn")
+                if g is None:
+                    return
+                g = g.reshape(B, n).float().contiguous()
+                dl = torch.empty((B, n), dtype=torch.float32, device=x.device)
+                call("mpn_softmax_rows_backward", ops.ptr(out), ops.ptr(g), ops.ptr(o.t), ops.ptr(dl), B, n, ops.stream_ptr())
+                if self.compute_dtype == torch.bfloat16:
+                    d = torch.empty((B, 1, 1, n), dtype=torch.bfloat16, device=x.device)
+                    ops.cast_bf16(dl, d)
+                else:
+                    d = dl.view(B, 1, 1, n)
+                ctx.set_grad(o, ops.Act(d, n))
+            ctx.tape.append(bwd)
+        out4 = out.view(B, prn.height, prn.width, 17)
+        out4 = self._wrap(ctx, ["prn"], [out4])[0]
+        return out4, [out4]
 
     # ------------------------------------------------------------------ losses
     @staticmethod
@@ -414,17 +443,31 @@ class poseNet(nn.Module):
             return 0
 
 
+class _BCEMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, y):
+        pc = p.detach().float().contiguous()
+        yc = y.detach().float().contiguous()
+        n = pc.numel()
+        chunks = call("mpn_bce_chunks", n)
+        part = ops.workspace(chunks * 4, pc.device, slot=7)
+        res = torch.empty(1, dtype=torch.float32, device=pc.device)
+        call("mpn_bce_mean_forward", ops.ptr(pc), ops.ptr(yc), n, ops.ptr(part), chunks, ops.ptr(res), ops.stream_ptr())
+        ctx.saved = (pc, yc, p.shape)
+        return res[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        pc, yc, shape = ctx.saved
+        dp = torch.empty_like(pc)
+        gs = g.detach().reshape(1).float().contiguous()
+        call("mpn_bce_mean_backward", ops.ptr(pc), ops.ptr(yc), ops.ptr(dp), pc.numel(), ops.ptr(gs), ops.stream_ptr())
+        return dp.view(shape), None
+
+
 def build_prn_loss(saved_for_loss, label):
     """posenet.py:427-445: BCELoss(size_average=True)(out, label)."""
     saved_for_log = OrderedDict()
-    out = saved_for_loss[0]
-    p = out.detach().float().contiguous()
-    y = label.detach().float().contiguous()
-    n = p.numel()
-    chunks = call("mpn_bce_chunks", n)
-    part = ops.workspace(chunks * 4, p.device, slot=7)
-    res = torch.empty(1, dtype=torch.float32, device=p.device)
-    call("mpn_bce_mean_forward", ops.ptr(p), ops.ptr(y), n, ops.ptr(part), chunks, ops.ptr(res), ops.stream_ptr())
-    total_loss = res[0]
+    total_loss = _BCEMean.apply(saved_for_loss[0], label)
     saved_for_log['PRN loss'] = total_loss.item()
     return total_loss, saved_for_log

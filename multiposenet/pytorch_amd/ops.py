@@ -224,6 +224,11 @@ def conv_wgrad(x, dy, dw, Cout, R, S, stride, pad, cin=None, x_geom=None):
 
 def bias_grad(dy, db, C):
     """db[C] (f32) += column sums of dy."""
+    v = 4 if dy.t.dtype == torch.float32 else 8
+    g = dy.Cs // v
+    if dy.P <= 256 or dy.Cs % v != 0 or (g & (g - 1)) != 0:
+        call("mpn_colsum_rows", ptr(dy.t), dtype_code(dy.t.dtype), dy.P, C, dy.Cs, ptr(db), stream_ptr())
+        return
     chunks = call("mpn_channel_sum_chunks", dy.P, dy.Cs, dtype_code(dy.t.dtype))
     ws = workspace(chunks * C * 4, dy.t.device, slot=2)
     call("mpn_channel_sum", ptr(dy.t), dtype_code(dy.t.dtype), dy.P, C, dy.Cs, ptr(ws), chunks, stream_ptr())

@@ -264,3 +264,67 @@ def test_full_size_batch_independence_and_determinism():
     assert torch.equal(d_all[1][2:3], d_1[1]) and torch.equal(d_all[0][2:3], d_1[0])
     assert torch.isfinite(p_all).all() and torch.isfinite(d_all[1]).all()
     report("full-size R101 480x480: batch independence + determinism OK")
+
+
+def test_prn_forward_loss_and_training_gradients():
+    """A14: PRN eval forward + BCE loss vs the reference golden (g7), gradients vs the CPU oracle (dropout
+    off), and dropout semantics (keep rate, 1/(1-p) scaling, same mask in backward)."""
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    from oracle import posenet_oracle as po, weightgen
+    g = gold("g7_prn.npz")
+    model = get_model(50, torch.float32)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if k.startswith("prn.")}
+    sd = weightgen.gen_state_dict(shapes, seed=7, flavour="he")
+    model.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    x = t(weightgen.uniform(7, "prn_in", (3, 56, 36, 17), 0.0, 1.0)).cuda()
+    label = t((weightgen.uniform(7, "prn_label", (3, 56, 36, 17)) < 0.01).astype(np.float32)).cuda()
+    model.eval()
+    with torch.no_grad():
+        out, saved = model([x, "prn_subnet"])
+        loss, log = poseNet.build_loss(saved, "prn_subnet", label)
+    assert out.shape == (3, 56, 36, 17) and saved[0] is out
+    close("prn out sample", out[:, ::7, ::6, :], t(g["out_sample"]), 1e-7, 2e-4)
+    assert np.array_equal(out.reshape(3, -1).argmax(1).cpu().numpy(), g["argmax"])
+    assert abs(loss.item() - g["loss"][0]) <= 2e-4 * g["loss"][0] and abs(log["PRN loss"] - loss.item()) < 1e-9
+    # gradients (eval mode: dropout is the identity, so the oracle can follow)
+    model.zero_grad()
+    out, saved = model([x, "prn_subnet"])
+    loss, _ = poseNet.build_loss(saved, "prn_subnet", label)
+    loss.backward()
+    osd = {k: t(v).clone().requires_grad_(True) for k, v in sd.items()}
+    oloss = po.prn_loss(po.prn_forward(osd, x.cpu()), label.cpu())
+    oloss.backward()
+    pd = dict(model.named_parameters())
+    for k in osd:
+        close("prn grad " + k, pd[k].grad, osd[k].grad, 2e-3 * osd[k].grad.abs().max().item(), 2e-3)
+    # dropout: ~half the hidden units dropped, survivors doubled, deterministic per call seed
+    from multiposenet.pytorch_amd import ops, _lib
+    v = torch.ones(1 << 16, device="cuda")
+    y1 = torch.empty_like(v); y2 = torch.empty_like(v)
+    _lib.call("mpn_dropout", ops.ptr(v), ops.ptr(y1), v.numel(), 1234, 0.5, 0, ops.stream_ptr())
+    _lib.call("mpn_dropout", ops.ptr(v), ops.ptr(y2), v.numel(), 1234, 0.5, 0, ops.stream_ptr())
+    keep = (y1 > 0).float().mean().item()
+    assert torch.equal(y1, y2) and abs(keep - 0.5) < 0.02 and set(y1.unique().tolist()) == {0.0, 2.0}
+    model.train()
+    out, saved = model([x, "prn_subnet"])
+    loss, _ = poseNet.build_loss(saved, "prn_subnet", label)
+    model.zero_grad()
+    loss.backward()
+    assert torch.isfinite(model.prn.dens1.weight.grad).all() and float(model.prn.dens1.weight.grad.abs().sum()) > 0
+
+
+def test_entire_net_all_images_equals_per_image_runs():
+    """cfg5-style inference: per-image threshold + NMS for a whole batch; entry b must equal the reference
+    semantics (image-0-only path) applied to image b alone — box index lists bit-exact, values identical."""
+    from oracle import weightgen
+    model = get_model(50, torch.float32)
+    model.eval()
+    img = t(weightgen.gen_images(11, 3, 128, 96)).cuda()
+    with torch.no_grad():
+        heat, dets = model.forward_all_images(img)
+        assert heat.shape == (3, 18, 32, 24) and len(dets) == 3
+        for b in range(3):
+            h1, d1 = model([img[b:b + 1].contiguous(), "both"])
+            assert torch.equal(h1, heat[b:b + 1])
+            assert d1[0].shape == dets[b][0].shape and d1[0].shape[0] > 0
+            assert torch.equal(d1[0], dets[b][0]) and torch.equal(d1[2], dets[b][2]) and torch.equal(d1[1], dets[b][1])
