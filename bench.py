@@ -145,6 +145,28 @@ def cpu_baseline(args):
         return {"value": None, "unit": "images/sec", "cores": host_cores(), "kind": "port", "sample": "timed out after 240 s"}
 
 
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of the dominant kernel from the last committed rocprofv3 --pmc passes
+    (profiles/r*_pmc_hbm_traffic.json, made by tools/pmc_summary.py: FETCH_SIZE and WRITE_SIZE in separate runs,
+    reads doubled per MI355X_MICROARCH.md).  PMC collection serialises kernels, so it cannot run inside the timed
+    bench; None when no profile is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    if not files:
+        return None
+    try:
+        prof = json.load(open(files[-1]))
+        key = "conv_wgrad_kernel<bf16, 128, 128>" if kernel_class.startswith("conv_wgrad") else kernel_class.replace(",", ", ")
+        best = None
+        for k in prof["kernels"]:
+            if k["kernel"].startswith(key.split(">")[0]):
+                if best is None or k["hbm_gb_per_step"] > best["hbm_gb_per_step"]:
+                    best = k
+        return None if best is None else int(best["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
@@ -235,7 +257,7 @@ def main():
             name, d = dom
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(ach / peak, 4), "traffic": None, "launches": d["n"],
+                               "frac": round(ach / peak, 4), "traffic": pmc_traffic(name), "launches": d["n"],
                                "avg_launch_us": round(d["ms"] * 1000.0 / max(d["n"], 1), 2),
                                "share_of_step": round(d["ms"] / (ms * args.steps), 4)}
             out["kernel_classes_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(ke.items(), key=lambda kv: -kv[1]["ms"])}
