@@ -17,6 +17,7 @@
 //     partials to a workspace and mpn_reduce_partials adds them into dW in a fixed order
 //     (deterministic; no atomics).  chunks == 1 accumulates straight into dW.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -269,6 +270,161 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(const MpnWgradParams
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// bf16 128x128 variant built on the CDNA4 LDS transpose read.  Both operands arrive pixel-major ([k][channel]),
+// the MFMA wants 8 consecutive k per lane: instead of re-packing in registers (above), tiles are written to LDS
+// exactly as loaded (one ds_write_b128 per 16 bytes) and fragments are gathered with ds_read_b64_tr_b16, which
+// hands lane i column i of a 4(k) x 16(channel) block.  Rows are 256 B (128 channels); the 16-byte chunk index
+// is XOR-swizzled with f(k) = 2*((k&3) | ((k>>3)&1)<<2) so that the 8 rows a 32-lane half touches in one
+// transpose read cover all 16 chunk slots (64 banks) exactly once, while a row's own 16 chunks stay a
+// permutation of one contiguous 256-byte line (conflict-free writes).
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ __forceinline__ int tr_swz(int k) { return 2 * ((k & 3) | (((k >> 3) & 1) << 2)); }
+
+__global__ void __launch_bounds__(256, 3) conv_wgrad_tr_kernel(const MpnWgradParams p, long chunk_pixels) {
+    constexpr int TM = 128, TN = 128, KP = 32;
+    constexpr int TILE_BYTES = KP * 256;                 // one operand tile
+    constexpr int BUF_BYTES = 2 * TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tilesM = (p.Cin + TM - 1) / TM, tilesN = (p.Cout + TN - 1) / TN;
+    const int taps = p.R * p.S;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % tilesN; bid /= tilesN;
+    const int tm = bid % tilesM; bid /= tilesM;
+    const int tap = bid % taps; bid /= taps;
+    const int chunk = bid;
+    const int r = tap / p.S, s = tap - r * p.S;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const long P = (long)p.B * p.Ho * p.Wo;
+    const long k_begin = (long)chunk * chunk_pixels;
+    long k_end = k_begin + chunk_pixels; if (k_end > P) k_end = P;
+    const bf16_t* __restrict__ X = (const bf16_t*)p.x;
+    const bf16_t* __restrict__ DY = (const bf16_t*)p.dy;
+    const int dy_cs = ((p.Cout + 31) / 32) * 32;
+
+    // load units: (k row, 16-byte chunk) ; 32 rows x 16 chunks = 512 units per operand = 2 per thread
+    int u_k[2], u_c[2], u_lds[2]; bool a_on[2], b_on[2]; PixState a_px[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int u = tid + 256 * q;
+        u_k[q] = u >> 4; u_c[q] = (u & 15) * 8;
+        u_lds[q] = u_k[q] * 256 + (((u & 15) ^ tr_swz(u_k[q])) * 16);
+        a_on[q] = (m0 + u_c[q]) < p.Cin;
+        b_on[q] = (n0 + u_c[q]) < dy_cs;
+        long pix = k_begin + u_k[q]; if (pix >= P) pix = P - 1;
+        a_px[q].init(pix, p.Ho, p.Wo);
+    }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    u32x4_t ra0[2], rb0[2], ra1[2], rb1[2];
+    const u32x4_t zero4 = (u32x4_t){0u, 0u, 0u, 0u};
+    long k0 = k_begin;
+
+    auto gload = [&](u32x4_t (&ra)[2], u32x4_t (&rb)[2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const long pix = k0 + u_k[q];
+            const int hi = a_px[q].ho * p.stride - p.pad + r, wi = a_px[q].wo * p.stride - p.pad + s;
+            const bool ok = a_on[q] && (pix < k_end) && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const long off = (long)a_px[q].b * p.x_sB + (long)hi * p.x_sH + (long)wi * p.x_sW + m0 + u_c[q];
+            ra[q] = ok ? *reinterpret_cast<const u32x4_t*>(X + off) : zero4;
+            a_px[q].advance(KP, p.Ho, p.Wo);
+            const bool okb = b_on[q] && (pix < k_end);
+            rb[q] = okb ? *reinterpret_cast<const u32x4_t*>(DY + pix * p.dy_sP + n0 + u_c[q]) : zero4;
+        }
+        k0 += KP;
+    };
+    auto lstore = [&](int buf, const u32x4_t (&ra)[2], const u32x4_t (&rb)[2]) {
+        unsigned char* la = lds + buf * BUF_BYTES;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            *reinterpret_cast<u32x4_t*>(la + u_lds[q]) = ra[q];
+            *reinterpret_cast<u32x4_t*>(la + TILE_BYTES + u_lds[q]) = rb[q];
+        }
+    };
+    // fragment gather: lane l -> rows k = 8*(l>>4) + 4*h + ((l&15)>>2), 8-byte piece (l&3) of the 16-channel block
+    const int g8 = (lane >> 4) * 8, li = lane & 15;
+    int row_off[2], row_swz[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = g8 + 4 * h + (li >> 2);
+        row_off[h] = k * 256;
+        row_swz[h] = tr_swz(k);
+    }
+    const int piece_chunk = (li & 3) >> 1, piece_half = (li & 1) * 8;
+    auto frag = [&](const unsigned char* tile, int c0) -> bf16x8_t {     // c0: first channel of the 16-wide block (multiple of 16)
+        const int lc = (c0 >> 3) + piece_chunk;
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(tile + row_off[0] + ((lc ^ row_swz[0]) * 16) + piece_half));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(tile + row_off[1] + ((lc ^ row_swz[1]) * 16) + piece_half));
+        struct { s16x4_t a, b; } pr = {lo, hi};
+        return __builtin_bit_cast(bf16x8_t, pr);
+    };
+    auto compute = [&](int buf) {
+        const unsigned char* la = lds + buf * BUF_BYTES;
+        const unsigned char* lb = la + TILE_BYTES;
+        bf16x8_t fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = frag(la, wm * 64 + i * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = frag(lb, wn * 64 + j * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+
+    const long span = k_end - k_begin;
+    const int nsteps = span > 0 ? (int)((span + KP - 1) / KP) : 0;
+    if (nsteps > 0) {
+        gload(ra0, rb0);
+        if (nsteps > 1) gload(ra1, rb1);
+        lstore(0, ra0, rb0);
+    }
+    __syncthreads();
+    int it = 0;
+    for (; it + 1 < nsteps; it += 2) {
+        if (it + 2 < nsteps) gload(ra0, rb0);
+        compute(0);
+        lstore(1, ra1, rb1);
+        __syncthreads();
+        if (it + 3 < nsteps) gload(ra1, rb1);
+        compute(1);
+        if (it + 2 < nsteps) lstore(0, ra0, rb0);
+        __syncthreads();
+    }
+    if (it < nsteps) compute(0);
+
+    const long NW = (long)p.Cout * taps * p.Cin;
+    float* __restrict__ dst = (p.chunks > 1) ? (p.ws + (long)chunk * NW) : p.dw;
+    const bool add = (p.chunks == 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cin = m0 + wm * 64 + i * 16 + (lane >> 4) * 4;
+        if (cin >= p.Cin) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cout = n0 + wn * 64 + j * 16 + (lane & 15);
+            if (cout >= p.Cout) continue;
+            float* q = dst + ((long)cout * taps + tap) * p.Cin + cin;
+            float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            if (add) {
+                const float4 o = *reinterpret_cast<const float4*>(q);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *reinterpret_cast<float4*>(q) = v;
+        }
+    }
+}
+
 __global__ void reduce_partials_kernel(const float* __restrict__ ws, int chunks, long n, float* __restrict__ dst, int accumulate) {
     const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= n) return;
@@ -327,7 +483,11 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st) {
     const long grid = tilesM * tilesN * p.R * p.S * p.chunks;
     if (grid <= 0 || grid > 0x7fffffffL || P >= 0x7fffffffL) return MPN_E_BADARG;
     int rc;
-    if (tm == 128) rc = launch_wgrad_n<T, 128>(p, tn, grid, chunk_pixels, st);
+    static const bool use_tr = !(getenv("MPN_WGRAD_NO_TR") && atoi(getenv("MPN_WGRAD_NO_TR")));
+    if (sizeof(T) == 2 && tm == 128 && tn == 128 && use_tr && p.Cin % 8 == 0) {
+        hipLaunchKernelGGL(conv_wgrad_tr_kernel, dim3((unsigned)grid), dim3(256), 0, st, p, chunk_pixels);
+        rc = mpn_launch_status();
+    } else if (tm == 128) rc = launch_wgrad_n<T, 128>(p, tn, grid, chunk_pixels, st);
     else if (tm == 64) rc = launch_wgrad_n<T, 64>(p, tn, grid, chunk_pixels, st);
     else rc = launch_wgrad_n<T, 32>(p, tn, grid, chunk_pixels, st);
     if (rc != 0) return rc;
