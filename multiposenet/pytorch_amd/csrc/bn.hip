@@ -43,18 +43,18 @@ __device__ __forceinline__ void load_coef(const float* __restrict__ p, int c0, i
     }
 }
 
-// block = 16 channels x 16 tile-slices
+// block = 4 channels x 64 tile-slices (the reduction over up to ~14k tiles is the only work: spread it wide)
 __global__ void bn_finalize_train_kernel(const float* __restrict__ stats, int tiles, int C, double count,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                          float* __restrict__ rm, float* __restrict__ rv, float momentum, float eps,
                                          float* __restrict__ mean, float* __restrict__ invstd,
                                          float* __restrict__ scale, float* __restrict__ shift) {
-    __shared__ double sh[2][16][17];
-    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    __shared__ double sh[2][64][5];
+    const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
-        for (int t = sl; t < tiles; t += 16) {
+        for (int t = sl; t < tiles; t += 64) {
             const float2 v = *reinterpret_cast<const float2*>(stats + ((long)t * C + c) * 2);
             s1 += (double)v.x; s2 += (double)v.y;
         }
@@ -63,8 +63,7 @@ __global__ void bn_finalize_train_kernel(const float* __restrict__ stats, int ti
     __syncthreads();
     if (sl == 0 && c < C) {
         s1 = 0.0; s2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { s1 += sh[0][k][cl]; s2 += sh[1][k][cl]; }
+        for (int k = 0; k < 64; ++k) { s1 += sh[0][k][cl]; s2 += sh[1][k][cl]; }
         const double mu = s1 / count;
         double var = s2 / count - mu * mu;
         if (var < 0.0) var = 0.0;
@@ -174,12 +173,12 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
                                        int train, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
-    __shared__ double sh[2][16][17];
-    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    __shared__ double sh[2][64][5];
+    const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
-        for (int t = sl; t < chunks; t += 16) {
+        for (int t = sl; t < chunks; t += 64) {
             const float2 v = *reinterpret_cast<const float2*>(partial + ((long)t * C + c) * 2);
             s1 += (double)v.x; s2 += (double)v.y;
         }
@@ -188,8 +187,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int ch
     __syncthreads();
     if (sl == 0 && c < C) {
         s1 = 0.0; s2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { s1 += sh[0][k][cl]; s2 += sh[1][k][cl]; }
+        for (int k = 0; k < 64; ++k) { s1 += sh[0][k][cl]; s2 += sh[1][k][cl]; }
         if (dbeta) dbeta[c] += (float)s1;
         if (dgamma) dgamma[c] += (float)s2;
         if (coef) {
@@ -263,7 +261,7 @@ extern "C" int mpn_bn_finalize_train(const float* stats, int tiles, int C, int64
                                      const float* beta, float* running_mean, float* running_var, float momentum,
                                      float eps, float* mean, float* invstd, float* scale, float* shift, void* stream) {
     MPN_CHECK_ARG(stats && tiles > 0 && C > 0 && count > 0 && mean && invstd && scale && shift);
-    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, stats, tiles, C,
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, stats, tiles, C,
                        (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
     return mpn_launch_status();
 }
@@ -322,7 +320,7 @@ extern "C" int mpn_bn_bwd_finalize(const float* partial, int chunks, int C, int6
                                    const float* invstd, int train, float* dgamma, float* dbeta, float* coef, void* stream) {
     MPN_CHECK_ARG(partial && chunks > 0 && C > 0 && count > 0);
     MPN_CHECK_ARG(!coef || (mean && invstd));
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
                        (double)count, gamma, mean, invstd, train, dgamma, dbeta, coef);
     return mpn_launch_status();
 }
