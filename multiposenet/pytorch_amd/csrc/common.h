@@ -11,12 +11,13 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even, NaN preserved (same rule torch uses for float -> bfloat16)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// round-to-nearest-even (the rule torch uses for float -> bfloat16); gfx950 has it in hardware
+// (v_cvt_pk_bf16_f32, two values per instruction), NaNs come back quiet.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t));
 }
 
 template <typename T> struct Elem;
@@ -58,10 +59,10 @@ template <> struct Vec16<bf16_t> {
     }
     __device__ __forceinline__ void store(bf16_t* p) const {
         uint4 t;
-        t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        t.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-        t.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+        t.x = pack_bf16x2(v[0], v[1]);
+        t.y = pack_bf16x2(v[2], v[3]);
+        t.z = pack_bf16x2(v[4], v[5]);
+        t.w = pack_bf16x2(v[6], v[7]);
         *reinterpret_cast<uint4*>(p) = t;
     }
 };

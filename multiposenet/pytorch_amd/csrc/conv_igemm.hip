@@ -66,8 +66,8 @@ template <> struct OutVec4<bf16_t> {
     }
     __device__ static __forceinline__ void store(bf16_t* p, const float v[4]) {
         uint2 t;
-        t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        t.x = pack_bf16x2(v[0], v[1]);
+        t.y = pack_bf16x2(v[2], v[3]);
         *reinterpret_cast<uint2*>(p) = t;
     }
     __device__ static __forceinline__ float round(float v) { return bf2f(f2bf(v)); }

@@ -508,8 +508,10 @@ extern "C" int mpn_conv_wgrad_chunks(const MpnWgradParams* p) {
     const int tm = pick_tile(p->Cin), tn = pick_tile(p->Cout);
     const long tiles = (long)((p->Cin + tm - 1) / tm) * ((p->Cout + tn - 1) / tn) * p->R * p->S;
     const long P = (long)p->B * p->Ho * p->Wo;
-    long want = (1536 + tiles - 1) / tiles;           // ~6 workgroups per CU queued (measured better than 3: latency-bound slices)
-    const long maxc = (P + 511) / 512;                 // keep >= 512 pixels per slice
+    static const long target = getenv("MPN_WGRAD_TARGET") ? atol(getenv("MPN_WGRAD_TARGET")) : 1536;
+    static const long minpix = getenv("MPN_WGRAD_MINPIX") ? atol(getenv("MPN_WGRAD_MINPIX")) : 512;
+    long want = (target + tiles - 1) / tiles;          // ~6 workgroups per CU queued (measured better than 3: latency-bound slices)
+    const long maxc = (P + minpix - 1) / minpix;       // keep >= 512 pixels per slice
     if (want > maxc) want = maxc;
     if (want < 1) want = 1;
     if (want > 256) want = 256;

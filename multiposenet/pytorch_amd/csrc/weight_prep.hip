@@ -19,10 +19,10 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __re
         const float4 a = *reinterpret_cast<const float4*>(src + i);
         const float4 b = *reinterpret_cast<const float4*>(src + i + 4);
         uint4 o;
-        o.x = (uint32_t)f2bf(a.x) | ((uint32_t)f2bf(a.y) << 16);
-        o.y = (uint32_t)f2bf(a.z) | ((uint32_t)f2bf(a.w) << 16);
-        o.z = (uint32_t)f2bf(b.x) | ((uint32_t)f2bf(b.y) << 16);
-        o.w = (uint32_t)f2bf(b.z) | ((uint32_t)f2bf(b.w) << 16);
+        o.x = pack_bf16x2(a.x, a.y);
+        o.y = pack_bf16x2(a.z, a.w);
+        o.z = pack_bf16x2(b.x, b.y);
+        o.w = pack_bf16x2(b.z, b.w);
         *reinterpret_cast<uint4*>(dst + i) = o;
     } else {
         for (long k = i; k < n; ++k) dst[k] = f2bf(src[k]);

@@ -24,25 +24,32 @@ SHAPES_ALL = [
 
 
 SHAPES = SHAPES_ALL if os.environ.get('MB_ALL', '1') == '1' else SHAPES_ALL[:3]
+if os.environ.get('MB_ONLY'):
+    SHAPES = [SHAPES_ALL[int(i)] for i in os.environ['MB_ONLY'].split(',')]
 WGRAD = os.environ.get('MB_WGRAD', '1') == '1'
 
 
 def main():
     dt = torch.bfloat16
     dev = "cuda"
+    cold = os.environ.get('MB_COLD', '0') == '1'
     for name, B, H, W, Cin, Cout, k, stride, pad, stats in SHAPES:
-        x = ops.Act(torch.randn(B, H, W, Cin, device=dev).to(dt), Cin)
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        set_bytes = 2 * B * (H * W * Cin + Ho * Wo * Cout)
+        nsets = max(2, min(64, int(800e6 // set_bytes) + 1)) if cold else 1   # cycle > MALL (256 MB) worth of operands
+        xs = [ops.Act(torch.randn(B, H, W, Cin, device=dev).to(dt), Cin) for _ in range(nsets)]
+        outs = [ops.Act.empty(B, Ho, Wo, Cout, dt, dev) for _ in range(nsets)]
+        x, out = xs[0], outs[0]
         w = (torch.randn(Cout, k, k, Cin, device=dev) / (Cin * k * k) ** 0.5).to(dt)
         bias = None if stats else torch.randn(Cout, device=dev)
-        out = ops.Act.empty(B, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1, Cout, dt, dev)
         for _ in range(3):
             ops.conv_forward(x, w, Cout, k, k, stride, pad, bias=bias, want_stats=stats, out=out)
         torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        n = 20
+        n = 20 if not cold else max(20, nsets)
         e0.record()
-        for _ in range(n):
-            ops.conv_forward(x, w, Cout, k, k, stride, pad, bias=bias, want_stats=stats, out=out)
+        for i in range(n):
+            ops.conv_forward(xs[i % nsets], w, Cout, k, k, stride, pad, bias=bias, want_stats=stats, out=outs[i % nsets])
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1000 / n
@@ -52,14 +59,16 @@ def main():
         if not WGRAD:
             continue
         # wgrad of the same layer
-        dy = ops.Act(torch.randn(out.t.shape, device=dev).to(dt), Cout)
+        dys = outs
+        for o in dys:
+            o.t.normal_()
         dw = torch.zeros(Cout, k, k, Cin, device=dev)
         for _ in range(2):
-            ops.conv_wgrad(x, dy, dw, Cout, k, k, stride, pad)
+            ops.conv_wgrad(x, dys[0], dw, Cout, k, k, stride, pad)
         torch.cuda.synchronize()
         e0.record()
-        for _ in range(n):
-            ops.conv_wgrad(x, dy, dw, Cout, k, k, stride, pad)
+        for i in range(n):
+            ops.conv_wgrad(xs[i % nsets], dys[i % nsets], dw, Cout, k, k, stride, pad)
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1000 / n
