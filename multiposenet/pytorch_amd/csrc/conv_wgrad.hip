@@ -37,6 +37,16 @@ struct PixState {      // incremental (b, ho, wo) walker over the dense output-p
         wo += n;
         while (wo >= Wo) { wo -= Wo; if (++ho == Ho) { ho = 0; ++b; } }
     }
+    // branch-free advance by a fixed pixel count pre-split into mixed-radix digits (db, dh, dw): n = (db*Ho + dh)*Wo + dw
+    __device__ __forceinline__ void advance_digits(int db, int dh, int dw, int Ho, int Wo) {
+        wo += dw;
+        const int c0 = wo >= Wo ? 1 : 0;
+        wo -= c0 ? Wo : 0;
+        ho += dh + c0;
+        const int c1 = ho >= Ho ? 1 : 0;
+        ho -= c1 ? Ho : 0;
+        b += db + c1;
+    }
     __device__ __forceinline__ PixState next(int Ho, int Wo) const {
         PixState q = *this;
         if (++q.wo == Wo) { q.wo = 0; if (++q.ho == Ho) { q.ho = 0; ++q.b; } }
@@ -425,6 +435,171 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_tr_kernel(const MpnWgradPar
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the transpose-read kernel (the default bf16 128x128 path).  Operand tiles go HBM -> LDS with
+// `buffer_load_dwordx4 ... lds` (no staging registers, no ds_write pass) into a 3-deep ring, two k-steps ahead of
+// the MFMAs.  The DMA destination is lane-linear (M0 base + lane*16), so the chunk swizzle of the tile image is
+// applied on the SOURCE side: the lane that owns LDS slot j of row k fetches channel chunk j ^ tr_swz(k).
+// Out-of-range lanes (halo taps, channel tail, pixels past the slice) carry an offset beyond num_records and the
+// hardware writes zeros — the dY descriptor is clipped to the slice end, so tail pixels need no per-step mask.
+// The loads are inline asm, invisible to the compiler's waitcnt bookkeeping: completion is counted by hand
+// (`s_waitcnt vmcnt(4)` = everything but the newest k-step's four loads has landed) and the barrier is the raw
+// s_barrier, so the ring never drains inside the loop.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ i32x4_t make_rsrc(const void* base, unsigned bytes) {
+    const uint64_t a = (uint64_t)base;
+    i32x4_t r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+__device__ __forceinline__ void lds_dma16(unsigned voff, i32x4_t rsrc, unsigned soff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+}
+
+constexpr unsigned DMA_OOB = 0x80000000u;     // tensors are < 2 GB (launcher check): marker + soffset never wraps
+
+__global__ void __launch_bounds__(256, 3) conv_wgrad_dma_kernel(const MpnWgradParams p, long chunk_pixels) {
+    constexpr int TM = 128, TN = 128, KP = 32, NST = 3;
+    constexpr int TILE_BYTES = KP * 256;                 // one operand tile
+    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tilesM = (p.Cin + TM - 1) / TM, tilesN = (p.Cout + TN - 1) / TN;
+    const int taps = p.R * p.S;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % tilesN; bid /= tilesN;
+    const int tm = bid % tilesM; bid /= tilesM;
+    const int tap = bid % taps; bid /= taps;
+    const int chunk = bid;
+    const int r = tap / p.S, s = tap - r * p.S;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const long P = (long)p.B * p.Ho * p.Wo;
+    const long k_begin = (long)chunk * chunk_pixels;
+    long k_end = k_begin + chunk_pixels; if (k_end > P) k_end = P;
+    const int dy_cs = ((p.Cout + 31) / 32) * 32;
+
+    const i32x4_t rsrc_x = make_rsrc(p.x, (unsigned)((long)p.B * p.x_sB * 2));
+    const i32x4_t rsrc_dy = make_rsrc(p.dy, (unsigned)((k_end > k_begin ? k_end : 0) * (long)p.dy_sP * 2));
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const unsigned wave_rows = (unsigned)__builtin_amdgcn_readfirstlane(wave) * 8u;
+
+    // DMA units: instruction q of wave w fills rows 8w+4q .. 8w+4q+3 of a tile (1 KiB); lane -> row (lane>>4), slot (lane&15)
+    unsigned b_voff[2]; int a_chan[2]; bool a_on[2]; PixState a_px[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = (int)wave_rows + 4 * q + (lane >> 4);
+        const int chan = (((lane & 15) ^ tr_swz(row)) * 8);
+        a_chan[q] = m0 + chan;
+        a_on[q] = (m0 + chan) < p.Cin;
+        long pix = k_begin + row; if (pix >= P) pix = P - 1;     // beyond-the-end rows meet zero dY rows
+        a_px[q].init(pix, p.Ho, p.Wo);
+        b_voff[q] = ((n0 + chan) < dy_cs) ? (unsigned)(((k_begin + row) * (long)p.dy_sP + n0 + chan) * 2) : DMA_OOB;
+    }
+    const unsigned b_step = (unsigned)(KP * p.dy_sP * 2);
+    unsigned b_soff = 0;
+    const int adv_t = KP / p.Wo, adv_w = KP - adv_t * p.Wo, adv_b = adv_t / p.Ho, adv_h = adv_t - adv_b * p.Ho;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](unsigned stage) {       // queue one k-step (4 DMA instructions per wave) into ring slot `stage`
+        const unsigned st = lds_base + stage * STAGE_BYTES + wave_rows * 256u;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int hi = a_px[q].ho * p.stride - p.pad + r, wi = a_px[q].wo * p.stride - p.pad + s;
+            const bool ok = a_on[q] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const unsigned off = ((unsigned)a_px[q].b * (unsigned)p.x_sB + (unsigned)hi * (unsigned)p.x_sH +
+                                  (unsigned)wi * (unsigned)p.x_sW + (unsigned)a_chan[q]) * 2u;
+            lds_dma16(ok ? off : DMA_OOB, rsrc_x, 0u, __builtin_amdgcn_readfirstlane(st + q * 1024u));
+            a_px[q].advance_digits(adv_b, adv_h, adv_w, p.Ho, p.Wo);
+            lds_dma16(b_voff[q], rsrc_dy, b_soff, __builtin_amdgcn_readfirstlane(st + TILE_BYTES + q * 1024u));
+        }
+        b_soff += b_step;
+    };
+
+    const int g8 = (lane >> 4) * 8, li = lane & 15;
+    int row_off[2], row_swz[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = g8 + 4 * h + (li >> 2);
+        row_off[h] = k * 256;
+        row_swz[h] = tr_swz(k);
+    }
+    const int piece_chunk = (li & 3) >> 1, piece_half = (li & 1) * 8;
+    auto frag = [&](const unsigned char* tile, int c0) -> bf16x8_t {
+        const int lc = (c0 >> 3) + piece_chunk;
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(tile + row_off[0] + ((lc ^ row_swz[0]) * 16) + piece_half));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(tile + row_off[1] + ((lc ^ row_swz[1]) * 16) + piece_half));
+        struct { s16x4_t a, b; } pr = {lo, hi};
+        return __builtin_bit_cast(bf16x8_t, pr);
+    };
+    auto compute = [&](unsigned stage) {
+        const unsigned char* la = lds + stage * STAGE_BYTES;
+        const unsigned char* lb = la + TILE_BYTES;
+        bf16x8_t fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = frag(la, wm * 64 + i * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = frag(lb, wn * 64 + j * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+
+    const long span = k_end - k_begin;
+    const int nsteps = span > 0 ? (int)((span + KP - 1) / KP) : 0;
+    // steps past the slice end are still queued (their dY rows are out of range -> zeros, never consumed) so the
+    // outstanding-load count is the same in every iteration
+    issue(0u);
+    issue(1u);
+    unsigned cur = 0u, nxt = 2u;
+    for (int it = 0; it < nsteps; ++it) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // k-step `it` has landed (this wave's part)
+        __builtin_amdgcn_s_barrier();                          // ... everyone's part; and slot `nxt` is no longer being read
+        issue(nxt);
+        compute(cur);
+        cur = (cur == NST - 1) ? 0u : cur + 1u;
+        nxt = (nxt == NST - 1) ? 0u : nxt + 1u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const long NW = (long)p.Cout * taps * p.Cin;
+    float* __restrict__ dst = (p.chunks > 1) ? (p.ws + (long)chunk * NW) : p.dw;
+    const bool add = (p.chunks == 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cin = m0 + wm * 64 + i * 16 + (lane >> 4) * 4;
+        if (cin >= p.Cin) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cout = n0 + wn * 64 + j * 16 + (lane & 15);
+            if (cout >= p.Cout) continue;
+            float* q = dst + ((long)cout * taps + tap) * p.Cin + cin;
+            float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            if (add) {
+                const float4 o = *reinterpret_cast<const float4*>(q);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *reinterpret_cast<float4*>(q) = v;
+        }
+    }
+}
+
 __global__ void reduce_partials_kernel(const float* __restrict__ ws, int chunks, long n, float* __restrict__ dst, int accumulate) {
     const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= n) return;
@@ -484,8 +659,11 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st) {
     if (grid <= 0 || grid > 0x7fffffffL || P >= 0x7fffffffL) return MPN_E_BADARG;
     int rc;
     static const bool use_tr = !(getenv("MPN_WGRAD_NO_TR") && atoi(getenv("MPN_WGRAD_NO_TR")));
+    static const bool use_dma = !(getenv("MPN_WGRAD_NO_DMA") && atoi(getenv("MPN_WGRAD_NO_DMA")));
+    const bool small = (long)p.B * p.x_sB * 2 < 0x7fffffffL && P * p.dy_sP * 2 < 0x7fffffffL;      // 32-bit buffer offsets
     if (sizeof(T) == 2 && tm == 128 && tn == 128 && use_tr && p.Cin % 8 == 0) {
-        hipLaunchKernelGGL(conv_wgrad_tr_kernel, dim3((unsigned)grid), dim3(256), 0, st, p, chunk_pixels);
+        if (use_dma && small) hipLaunchKernelGGL(conv_wgrad_dma_kernel, dim3((unsigned)grid), dim3(256), 0, st, p, chunk_pixels);
+        else hipLaunchKernelGGL(conv_wgrad_tr_kernel, dim3((unsigned)grid), dim3(256), 0, st, p, chunk_pixels);
         rc = mpn_launch_status();
     } else if (tm == 128) rc = launch_wgrad_n<T, 128>(p, tn, grid, chunk_pixels, st);
     else if (tm == 64) rc = launch_wgrad_n<T, 64>(p, tn, grid, chunk_pixels, st);

@@ -36,7 +36,8 @@ def main():
     for name, B, H, W, Cin, Cout, k, stride, pad, stats in SHAPES:
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         set_bytes = 2 * B * (H * W * Cin + Ho * Wo * Cout)
-        nsets = max(2, min(64, int(800e6 // set_bytes) + 1)) if cold else 1   # cycle > MALL (256 MB) worth of operands
+        cold_bytes = float(os.environ.get('MB_COLD_BYTES', '800e6'))
+        nsets = max(2, min(4096, int(cold_bytes // set_bytes) + 1)) if cold else 1   # cycle > MALL (256 MB) worth of operands
         xs = [ops.Act(torch.randn(B, H, W, Cin, device=dev).to(dt), Cin) for _ in range(nsets)]
         outs = [ops.Act.empty(B, Ho, Wo, Cout, dt, dev) for _ in range(nsets)]
         x, out = xs[0], outs[0]
@@ -46,7 +47,8 @@ def main():
             ops.conv_forward(x, w, Cout, k, k, stride, pad, bias=bias, want_stats=stats, out=out)
         torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        n = 20 if not cold else max(20, nsets)
+        n = int(os.environ.get('MB_ITERS', '20'))
+        n = n if not cold else max(n, nsets)
         e0.record()
         for i in range(n):
             ops.conv_forward(xs[i % nsets], w, Cout, k, k, stride, pad, bias=bias, want_stats=stats, out=outs[i % nsets])

@@ -28,13 +28,12 @@ def main():
         if r[2] / tot < 0.0002:
             continue
         print("%-98s %7d %10.2f %9.3f %9.1f %9.1f %6.2f" % (short(r[0]), r[1], r[2], r[2] / steps, r[3], r[5], 100 * r[2] / tot))
-    for kn in ("conv_igemm_kernel<unsigned short, 128, 128>", "conv_igemm_kernel<unsigned short, 64, 128>", "conv_wgrad_kernel<unsigned short, 128, 128>"):
-        g = cur.execute("select grid_x/workgroup_x, count(*), sum(end-start)/1e6, avg(end-start)/1e3 from kernels where name like ? "
-                        "group by grid_x order by 3 desc", ("%" + kn + "%",)).fetchall()
-        if not g:
-            continue
+    names = [r[0] for r in rows if ("conv_igemm_kernel" in r[0] or "conv_wgrad" in r[0]) and r[2] / tot > 0.02]
+    for kn in names:
+        g = cur.execute("select grid_x/workgroup_x, count(*), sum(end-start)/1e6, avg(end-start)/1e3 from kernels where name = ? "
+                        "group by grid_x order by 3 desc", (kn,)).fetchall()
         print("\n# %s by launch geometry (workgroups)" % short(kn))
-        for r in g[:14]:
+        for r in g[:12]:
             print("  blocks=%7d calls/step=%6.1f  ms/step=%8.3f  avg=%9.1f us" % (r[0], r[1] / steps, r[2] / steps, r[3]))
 
 
