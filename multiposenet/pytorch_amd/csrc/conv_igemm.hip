@@ -11,8 +11,8 @@
 //   * K is walked in 64-byte chunks (32 bf16 / 16 f32 channels of one tap); a chunk never straddles
 //     a tap, so the gather is one predicated 16-byte load per lane and halo pixels are zero-filled
 //     in registers (no im2col buffer, no padded copy of the activations).
-//   * 256 threads = 4 waves; block tile TC x 128 pixels; register-prefetched, double-buffered LDS
-//     (80-byte rows: 64 B data + 16 B pad so the 16-lane ds_read_b128 groups spread over banks).
+//   * 256 threads = 4 waves; block tile TC x 128 pixels; tiles travel HBM -> LDS by DMA (buffer_load ... lds)
+//     into a 3-deep ring with hand-counted vmcnt; 64-byte rows, 16-byte pieces XOR-swizzled against bank conflicts.
 //   * bf16: v_mfma_f32_16x16x32_bf16 (fp32 accumulate); f32: v_mfma_f32_16x16x4_f32 (exact fp32,
 //     bit-identical to an fmaf chain) — the f32 instantiation is the parity path.
 //   * epilogue fuses per-channel scale, bias, residual (same-size or nearest-upsampled: the FPN
@@ -27,7 +27,6 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
-constexpr int LDS_ROW = 80;
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -83,9 +82,14 @@ struct ConvCfg {
     static constexpr int WTP = TP / WAVES_P;     // wave tile, pixels
     static constexpr int MC = WTC / 16;
     static constexpr int MP = WTP / 16;
-    static constexpr int A_PER_T = (TC * 4 + 255) / 256;
-    static constexpr int B_PER_T = (TP * 4 + 255) / 256;
-    static constexpr int BUF_BYTES = (TC + TP) * LDS_ROW;
+    // LDS ring: per stage an A tile (TA_ROWS couts x 64 B) and a B tile (TP pixels x 64 B), rows back to back
+    static constexpr int TA_ROWS = TC < 64 ? 64 : TC;        // one 1-KiB DMA instruction per wave at least
+    static constexpr int A_PER_W = TA_ROWS / 64;             // DMA instructions per wave per k-step
+    static constexpr int B_PER_W = TP / 64;
+    static constexpr int LPS = A_PER_W + B_PER_W;
+    static constexpr int A_BYTES = TA_ROWS * 64;
+    static constexpr int STAGE_BYTES = (TA_ROWS + TP) * 64;
+    static constexpr int NST = 3;
 };
 
 // Epilogue.  Phase A (accumulator layout: lane = 4 consecutive couts of one pixel): scale, bias, residual,
@@ -119,7 +123,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
     constexpr int LPP = C::WTC * OSZ / 16;                    // lanes per pixel in the store phase
     constexpr int PPI = 64 / LPP;                             // pixels per store instruction
     constexpr int EV = 16 / OSZ;                              // elements per 16-byte store
-    static_assert(4 * REGION <= 2 * C::BUF_BYTES, "staging area must fit the main-loop LDS");
+    static_assert(4 * REGION <= C::NST * C::STAGE_BYTES, "staging area must fit the main-loop LDS");
     const unsigned HoWo = (unsigned)p.Ho * (unsigned)p.Wo;
     const unsigned P = (unsigned)p.B * HoWo;           // launcher guarantees P < 2^31
     OT* __restrict__ Y = (OT*)p.y;
@@ -268,10 +272,40 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
     }
 }
 
+// LDS-DMA plumbing (see conv_wgrad.hip for the probe-verified semantics): `buffer_load_dwordx4 ... lds` writes
+// 16 bytes per lane at M0 + lane*16, zero for lanes whose voffset + soffset is beyond num_records.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ i32x4_t make_rsrc(const void* base, unsigned bytes) {
+    const uint64_t a = (uint64_t)base;
+    i32x4_t r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+__device__ __forceinline__ void lds_dma16(unsigned voff, i32x4_t rsrc, unsigned soff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// Main kernel.  Operand tiles travel HBM -> LDS by DMA into a 3-deep ring, two k-steps ahead of the MFMAs; no
+// staging registers, no ds_write pass.  A tile row is one 64-byte k-chunk of a cout (A) or of a gathered pixel (B);
+// rows are stored back to back (the DMA destination is lane-linear) and the four 16-byte pieces of row `i` are
+// XOR-swizzled with (i >> 2) & 3 — applied on the source side: the lane that owns LDS slot (row, j) fetches piece
+// j ^ ((row >> 2) & 3) — so the 16 rows x 1 piece a ds_read_b128 lane group touches cover all 64 banks once.
+// Halo pixels, rows past Cout / past the last pixel carry an out-of-range offset and arrive as zeros.  The loads
+// are invisible to the compiler's waitcnt pass: completion is counted by hand (vmcnt(LPS) = everything but the
+// newest k-step has landed) and the barrier is the raw s_barrier, so the ring never drains inside the loop.
 template <typename T, int TC, int TP, bool OUTF32, bool GENERAL>
 __global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams p, const int dbg) {
     using C = ConvCfg<T, TC, TP>;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * C::BUF_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[C::NST * C::STAGE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave / C::WAVES_P, wp = wave % C::WAVES_P;
@@ -285,35 +319,34 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams 
     constexpr unsigned TS = (unsigned)sizeof(T);
     const long KW = (long)p.R * p.S * p.Cin;
     const int sh = p.stride - 1;          // dgrad supports stride 1 or 2
-    // Operands are read through buffer descriptors: 32-bit per-lane byte offsets, the k-chunk offset rides in
-    // the scalar soffset, and an out-of-range offset returns 0 — halo pixels and rows beyond Cout need no
-    // branch, no select and no 64-bit address arithmetic (launcher guarantees both tensors are < 4 GB).
+    // 32-bit per-lane byte offsets into buffer descriptors; the k-chunk offset rides in the scalar soffset (the
+    // launcher guarantees tensor bytes + one row < 4 GB so marker + soffset cannot wrap)
     const unsigned x_bytes = (unsigned)((long)p.B * p.x_sB * TS);
     const unsigned w_bytes = (unsigned)((long)p.Cout * KW * TS);
-    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, w_bytes, 0x00020000);
+    const i32x4_t rsrc_x = make_rsrc(p.x, x_bytes);
+    const i32x4_t rsrc_w = make_rsrc(p.w, w_bytes);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
 
-    unsigned a_voff[C::A_PER_T];
-    int a_lds[C::A_PER_T];
+    // DMA units: one instruction fills 16 consecutive tile rows (1 KiB); lane -> row (lane >> 2), slot (lane & 3)
+    const int u_row = lane >> 2;
+    const int u_piece = (lane & 3) ^ ((lane >> 4) & 3);          // source piece for this lane's slot
+    unsigned a_voff[C::A_PER_W];
 #pragma unroll
-    for (int q = 0; q < C::A_PER_T; ++q) {
-        const int u = tid + 256 * q;
-        const int row = u >> 2, ch = u & 3;
+    for (int q = 0; q < C::A_PER_W; ++q) {
+        const int row = ((int)wave_u * C::A_PER_W + q) * 16 + u_row;
         const int cout = c0 + row;
-        const bool ok = (u < TC * 4) && (cout < p.Cout);
-        a_voff[q] = ok ? (unsigned)(((long)cout * KW + ch * C::V) * TS) : w_bytes;
-        a_lds[q] = (u < TC * 4) ? row * LDS_ROW + ch * 16 : -1;
+        const bool ok = (row < TC) && (cout < p.Cout);
+        a_voff[q] = ok ? (unsigned)(((long)cout * KW + u_piece * C::V) * TS) : w_bytes;
     }
-    unsigned b_base[C::B_PER_T], b_voff[C::B_PER_T];
-    int b_h[C::B_PER_T], b_w[C::B_PER_T];
-    bool b_ok[C::B_PER_T];
-    int b_lds[C::B_PER_T];
+    unsigned b_base[C::B_PER_W], b_voff[C::B_PER_W];
+    int b_h[C::B_PER_W], b_w[C::B_PER_W];
+    bool b_ok[C::B_PER_W];
 #pragma unroll
-    for (int q = 0; q < C::B_PER_T; ++q) {
-        const int u = tid + 256 * q;
-        const int row = u >> 2, ch = u & 3;
+    for (int q = 0; q < C::B_PER_W; ++q) {
+        const int row = ((int)wave_u * C::B_PER_W + q) * 16 + u_row;
         const unsigned pix = (unsigned)p0 + row;
-        const bool ok = (u < TP * 4) && (pix < P);
+        const bool ok = pix < P;
         const unsigned pc = ok ? pix : 0u;
         const unsigned b = pc / HoWo;
         const unsigned rem = pc - b * HoWo;
@@ -321,9 +354,8 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams 
         b_ok[q] = ok;
         if (p.mode == 0) { b_h[q] = ho * p.stride - p.pad; b_w[q] = wo * p.stride - p.pad; }
         else             { b_h[q] = ho + p.pad;            b_w[q] = wo + p.pad; }
-        b_base[q] = (unsigned)(((long)b * p.x_sB + ch * C::V) * TS);
+        b_base[q] = (unsigned)(((long)b * p.x_sB + u_piece * C::V) * TS);
         b_voff[q] = x_bytes;
-        b_lds[q] = (u < TP * 4) ? (TC + row) * LDS_ROW + ch * 16 : -1;
     }
     const unsigned sH_b = (unsigned)(p.x_sH * TS), sW_b = (unsigned)(p.x_sW * TS);
 
@@ -336,14 +368,11 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams 
     const int nsteps = p.R * p.S * (p.Cin / C::KC);
     int r = 0, s = 0, cc = 0;
     int klin = 0;
-    // three register stages: loads run THREE k-steps ahead of the MFMAs (global latency ~1 us per hop is the
-    // critical path of a short k-step; one stage in flight while the other is written to LDS)
-    u32x4_t ra0[C::A_PER_T], rb0[C::B_PER_T], ra1[C::A_PER_T], rb1[C::B_PER_T], ra2[C::A_PER_T], rb2[C::B_PER_T];
 
-    auto gload = [&](u32x4_t (&ra)[C::A_PER_T], u32x4_t (&rb)[C::B_PER_T]) {
+    auto issue = [&](unsigned stage) {       // queue one k-step (LPS DMA instructions per wave) into ring slot `stage`
         if (cc == 0) {                       // new tap (uniform): per-row gather offsets, OOB offset for halo / dead rows
 #pragma unroll
-            for (int q = 0; q < C::B_PER_T; ++q) {
+            for (int q = 0; q < C::B_PER_W; ++q) {
                 int hi, wi;
                 bool ok = b_ok[q];
                 if (p.mode == 0) {
@@ -358,36 +387,29 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams 
             }
         }
         const unsigned so_w = (unsigned)klin * TS, so_x = (unsigned)cc * TS;
+        const unsigned st = lds_base + stage * C::STAGE_BYTES;
 #pragma unroll
-        for (int q = 0; q < C::A_PER_T; ++q)
-            ra[q] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, a_voff[q], so_w, 0));
+        for (int q = 0; q < C::A_PER_W; ++q)
+            lds_dma16(a_voff[q], rsrc_w, so_w, __builtin_amdgcn_readfirstlane(st + (wave_u * C::A_PER_W + q) * 1024u));
 #pragma unroll
-        for (int q = 0; q < C::B_PER_T; ++q)
-            rb[q] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, b_voff[q], so_x, 0));
-        // advance (tap, channel-chunk)
+        for (int q = 0; q < C::B_PER_W; ++q)
+            lds_dma16(b_voff[q], rsrc_x, so_x, __builtin_amdgcn_readfirstlane(st + C::A_BYTES + (wave_u * C::B_PER_W + q) * 1024u));
         klin += C::KC; cc += C::KC;
         if (cc == p.Cin) { cc = 0; if (++s == p.S) { s = 0; ++r; } }
     };
-    auto lstore = [&](int buf, const u32x4_t (&ra)[C::A_PER_T], const u32x4_t (&rb)[C::B_PER_T]) {
-        unsigned char* base = lds + buf * C::BUF_BYTES;
-#pragma unroll
-        for (int q = 0; q < C::A_PER_T; ++q)
-            if (a_lds[q] >= 0) *reinterpret_cast<u32x4_t*>(base + a_lds[q]) = ra[q];
-#pragma unroll
-        for (int q = 0; q < C::B_PER_T; ++q)
-            if (b_lds[q] >= 0) *reinterpret_cast<u32x4_t*>(base + b_lds[q]) = rb[q];
-    };
-    const int fa_off = (wc * C::WTC + (lane & 15)) * LDS_ROW + (lane >> 4) * 16;
-    const int fb_off = (TC + wp * C::WTP + (lane & 15)) * LDS_ROW + (lane >> 4) * 16;
-    auto compute = [&](int buf) {
-        const unsigned char* base = lds + buf * C::BUF_BYTES;
+    // fragment gather: lane -> row (lane & 15) of a 16-row group, k-piece (lane >> 4), un-swizzled by (row >> 2) & 3
+    const int f_off = (lane & 15) * 64 + (((lane >> 4) ^ ((lane >> 2) & 3)) * 16);
+    const int fa_off = wc * C::WTC * 64 + f_off;
+    const int fb_off = C::A_BYTES + wp * C::WTP * 64 + f_off;
+    auto compute = [&](unsigned stage) {
+        const unsigned char* base = lds + stage * C::STAGE_BYTES;
         u32x4_t fa[C::MC], fb[C::MP];
 #pragma unroll
         for (int i = 0; i < C::MC; ++i)
-            fa[i] = *reinterpret_cast<const u32x4_t*>(base + fa_off + i * 16 * LDS_ROW);
+            fa[i] = *reinterpret_cast<const u32x4_t*>(base + fa_off + i * 1024);
 #pragma unroll
         for (int j = 0; j < C::MP; ++j)
-            fb[j] = *reinterpret_cast<const u32x4_t*>(base + fb_off + j * 16 * LDS_ROW);
+            fb[j] = *reinterpret_cast<const u32x4_t*>(base + fb_off + j * 1024);
 #pragma unroll
         for (int i = 0; i < C::MC; ++i)
 #pragma unroll
@@ -395,30 +417,18 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams 
     };
     if (dbg & 32) return;                    // ablation: prologue only
 
-    gload(ra0, rb0);
-    if (nsteps > 1) gload(ra1, rb1);
-    if (nsteps > 2) gload(ra2, rb2);
-    lstore(0, ra0, rb0);
-    __syncthreads();
-    // step k: issue loads of step k+3 into the register stage that was just drained, run the MFMAs of step k
-    // from LDS buffer k%2, write step k+1's registers to the other buffer, one barrier.  Unrolled by 6 so
-    // every register stage / LDS buffer index is a compile-time constant.
-#define MPN_STEP(J, RA_LD, RB_LD, RA_ST, RB_ST)                                   \
-    if (it + (J) < nsteps) {                                                      \
-        if (it + (J) + 3 < nsteps) gload(RA_LD, RB_LD);                           \
-        compute((J) & 1);                                                         \
-        if (it + (J) + 1 < nsteps) lstore(((J) + 1) & 1, RA_ST, RB_ST);           \
-        __syncthreads();                                                          \
+    issue(0u);
+    if (nsteps > 1) issue(1u);
+    unsigned cur = 0u, nxt = 2u;
+    for (int it = 0; it < nsteps; ++it) {
+        if (it + 1 < nsteps) wait_vmcnt<C::LPS>(); else wait_vmcnt<0>();     // k-step `it` has landed (this wave's part)
+        __builtin_amdgcn_s_barrier();                                          // ... everyone's; slot `nxt` is free again
+        if (it + 2 < nsteps) issue(nxt);
+        compute(cur);
+        cur = (cur == C::NST - 1) ? 0u : cur + 1u;
+        nxt = (nxt == C::NST - 1) ? 0u : nxt + 1u;
     }
-    for (int it = 0; it < nsteps; it += 6) {
-        MPN_STEP(0, ra0, rb0, ra1, rb1)
-        MPN_STEP(1, ra1, rb1, ra2, rb2)
-        MPN_STEP(2, ra2, rb2, ra0, rb0)
-        MPN_STEP(3, ra0, rb0, ra1, rb1)
-        MPN_STEP(4, ra1, rb1, ra2, rb2)
-        MPN_STEP(5, ra2, rb2, ra0, rb0)
-    }
-#undef MPN_STEP
+    __syncthreads();                          // the epilogue re-uses the ring as its staging area
 
     if (dbg & 16) { if (acc[0][0][0] == 123.456f) ((float*)p.y)[0] = 1.f; return; }   // ablation: no epilogue
     if (OUTF32) conv_epilogue<T, float, TC, TP, GENERAL>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg);
@@ -488,7 +498,8 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     MPN_CHECK_ARG(!((p.res_mode || p.accumulate) && p.act));
     {   // buffer descriptors address at most 4 GB per operand
         const int64_t ts = p.dtype == MPN_F32 ? 4 : 2;
-        if ((int64_t)p.B * p.x_sB * ts >= 0xfffffff0LL || (int64_t)p.Cout * p.R * p.S * p.Cin * ts >= 0xfffffff0LL) return MPN_E_UNSUPPORTED;
+        const int64_t row = (int64_t)p.R * p.S * p.Cin * ts;
+        if ((int64_t)p.B * p.x_sB * ts + row >= 0xfffffff0LL || (int64_t)(p.Cout + 1) * row >= 0xfffffff0LL) return MPN_E_UNSUPPORTED;
     }          // activation is applied before the residual stage
     hipStream_t st = (hipStream_t)stream;
     if (p.dtype == MPN_F32) return launch_conv<float, false>(p, st);       // OT == T == float
