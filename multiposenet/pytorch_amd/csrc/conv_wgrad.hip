@@ -465,8 +465,9 @@ __device__ __forceinline__ void lds_dma16(unsigned voff, i32x4_t rsrc, unsigned 
 
 constexpr unsigned DMA_OOB = 0x80000000u;     // tensors are < 2 GB (launcher check): marker + soffset never wraps
 
-__global__ void __launch_bounds__(256, 3) conv_wgrad_dma_kernel(const MpnWgradParams p, long chunk_pixels) {
-    constexpr int TM = 128, TN = 128, KP = 32, NST = 3;
+template <int NST>
+__global__ void __launch_bounds__(256, NST == 3 ? 3 : 2) conv_wgrad_dma_kernel(const MpnWgradParams p, long chunk_pixels) {
+    constexpr int TM = 128, TN = 128, KP = 32;
     constexpr int TILE_BYTES = KP * 256;                 // one operand tile
     constexpr int STAGE_BYTES = 2 * TILE_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE_BYTES];
@@ -565,11 +566,11 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_dma_kernel(const MpnWgradPa
     const int nsteps = span > 0 ? (int)((span + KP - 1) / KP) : 0;
     // steps past the slice end are still queued (their dY rows are out of range -> zeros, never consumed) so the
     // outstanding-load count is the same in every iteration
-    issue(0u);
-    issue(1u);
-    unsigned cur = 0u, nxt = 2u;
+#pragma unroll
+    for (int q = 0; q < NST - 1; ++q) issue((unsigned)q);
+    unsigned cur = 0u, nxt = NST - 1;
     for (int it = 0; it < nsteps; ++it) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // k-step `it` has landed (this wave's part)
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (NST - 2)) : "memory");      // k-step `it` has landed (this wave's part)
         __builtin_amdgcn_s_barrier();                          // ... everyone's part; and slot `nxt` is no longer being read
         issue(nxt);
         compute(cur);
@@ -662,7 +663,14 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st) {
     static const bool use_dma = !(getenv("MPN_WGRAD_NO_DMA") && atoi(getenv("MPN_WGRAD_NO_DMA")));
     const bool small = (long)p.B * p.x_sB * 2 < 0x7fffffffL && P * p.dy_sP * 2 < 0x7fffffffL;      // 32-bit buffer offsets
     if (sizeof(T) == 2 && tm == 128 && tn == 128 && use_tr && p.Cin % 8 == 0) {
-        if (use_dma && small) hipLaunchKernelGGL(conv_wgrad_dma_kernel, dim3((unsigned)grid), dim3(256), 0, st, p, chunk_pixels);
+        static const int nst_env = getenv("MPN_WGRAD_NST") ? atoi(getenv("MPN_WGRAD_NST")) : 0;
+        // a launch that leaves each CU with ~2 workgroups affords a deeper ring (more k-steps of DMA in flight)
+        const int nst = nst_env ? nst_env : 3;       // deeper rings measured no faster (the loop is not DMA-latency-bound)
+        if (use_dma && small) {
+            if (nst == 5) hipLaunchKernelGGL(conv_wgrad_dma_kernel<5>, dim3((unsigned)grid), dim3(256), 0, st, p, chunk_pixels);
+            else if (nst == 4) hipLaunchKernelGGL(conv_wgrad_dma_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, p, chunk_pixels);
+            else hipLaunchKernelGGL(conv_wgrad_dma_kernel<3>, dim3((unsigned)grid), dim3(256), 0, st, p, chunk_pixels);
+        }
         else hipLaunchKernelGGL(conv_wgrad_tr_kernel, dim3((unsigned)grid), dim3(256), 0, st, p, chunk_pixels);
         rc = mpn_launch_status();
     } else if (tm == 128) rc = launch_wgrad_n<T, 128>(p, tn, grid, chunk_pixels, st);
@@ -686,9 +694,9 @@ extern "C" int mpn_conv_wgrad_chunks(const MpnWgradParams* p) {
     const int tm = pick_tile(p->Cin), tn = pick_tile(p->Cout);
     const long tiles = (long)((p->Cin + tm - 1) / tm) * ((p->Cout + tn - 1) / tn) * p->R * p->S;
     const long P = (long)p->B * p->Ho * p->Wo;
-    static const long target = getenv("MPN_WGRAD_TARGET") ? atol(getenv("MPN_WGRAD_TARGET")) : 1536;
+    static const long target = getenv("MPN_WGRAD_TARGET") ? atol(getenv("MPN_WGRAD_TARGET")) : 512;
     static const long minpix = getenv("MPN_WGRAD_MINPIX") ? atol(getenv("MPN_WGRAD_MINPIX")) : 512;
-    long want = (target + tiles - 1) / tiles;          // ~6 workgroups per CU queued (measured better than 3: latency-bound slices)
+    long want = (target + tiles - 1) / tiles;          // ~2 workgroups per CU: with the DMA ring long slices run near peak and partial-sum traffic dominates
     const long maxc = (P + minpix - 1) / minpix;       // keep >= 512 pixels per slice
     if (want > maxc) want = maxc;
     if (want < 1) want = 1;

@@ -13,8 +13,9 @@ DataParallel), computes its local-mean loss, and only gradients cross xGMI:
   * backward is a tape, so the engine knows the moment a parameter's last gradient contribution has
     been enqueued; when every parameter of a bucket is ready the bucket's all-reduce is issued with
     ``async_op=True`` (torch.distributed runs it on RCCL's own stream, ordered after the producing
-    kernels) and overlaps the remaining dgrad/wgrad work.  Buckets complete in reverse-forward order
-    (heads -> FPN -> layer4 ... conv1);
+    kernels — weight gradients run on the engine's side stream, so the collective is enqueued behind that
+    stream after it has been made to wait for the main one) and overlaps the remaining dgrad/wgrad work.
+    Buckets complete in reverse-forward order (heads -> FPN -> layer4 ... conv1);
   * ``finish()`` waits for the outstanding handles and averages (``ReduceOp.AVG`` on RCCL; SUM then
     an in-place scale on backends without AVG, e.g. gloo in the CPU tests).
 
@@ -38,6 +39,7 @@ class GradReducer(object):
         self.launched = 0
         backend = dist.get_backend(process_group)
         self.use_avg = backend == "nccl"
+        self.launch_stream = None      # set by the engine when weight gradients are produced on a side stream
 
     def _build(self):
         ar = self.arena
@@ -87,7 +89,16 @@ class GradReducer(object):
     def _launch(self, bk):
         view = self.arena.grad_flat[bk["start"]: bk["end"]]
         op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
-        h = dist.all_reduce(view, op=op, group=self.pg, async_op=True)
+        if self.launch_stream is not None:
+            # the bucket's gradients come from two streams (wgrad on the side stream, BN/bias pieces on the main one):
+            # order the collective after both without stalling the main stream
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.launch_stream):
+                self.launch_stream.wait_event(ev)
+                h = dist.all_reduce(view, op=op, group=self.pg, async_op=True)
+        else:
+            h = dist.all_reduce(view, op=op, group=self.pg, async_op=True)
         self.handles.append((h, view))
         self.launched += 1
         bk["pending"] = -1

@@ -11,6 +11,7 @@ is attached it is told as each parameter's gradient completes, so RCCL all-reduc
 arena slices overlap the rest of backward.
 """
 import ctypes
+import os
 
 import torch
 
@@ -31,6 +32,7 @@ class Ctx(object):
         self.wt = {}             # id(weight param) -> transposed operand
         self.uses = {}           # id(param) -> number of pending gradient contributions
         self.bn_train_ran = False
+        self.side_keep = []      # operands of side-stream launches, kept alive until the streams join
 
     def gbuf(self, act, dtype=None):
         """Gradient buffer for ``act``: returns (Act, existed)."""
@@ -65,6 +67,32 @@ class Engine(object):
     def __init__(self, model):
         self.m = model
         self._drop_calls = 0
+        self._side = None
+        self.overlap_wgrad = os.environ.get("MPN_SIDE_STREAM", "1") != "0"
+
+    def side_stream(self, device):
+        """Second HIP stream for weight/bias gradients.  They are off the backward critical path (only the
+        optimizer / all-reduce needs them), while dgrad -> BN backward -> dgrad is a serial chain of launches that
+        individually leave CUs idle (layer3/4 grids of 450-900 workgroups, HBM-bound BN passes): running the
+        wgrad of layer L beside the dgrad/BN work of layers < L fills those holes."""
+        if not self.overlap_wgrad or device.type != "cuda":
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
+
+    def _on_side(self, ctx, device, keep, fn):
+        """Run fn() on the side stream, ordered after everything enqueued so far on the current stream."""
+        side = self.side_stream(device)
+        if side is None:
+            fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        ctx.side_keep.append(keep)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            fn()
 
     # ------------------------------------------------------------------ weights
     @property
@@ -143,12 +171,19 @@ class Engine(object):
             else:
                 g.t.copy_(dy.t)
         ar = self.m._arena
-        if layer.weight.requires_grad:
-            ops.conv_wgrad(x, dy, ar.grad_seg(layer.weight), O, R, S, stride, pad)
-            self._grad_done(ctx, layer.weight)
-        if bias is not None and bias.requires_grad:
-            ops.bias_grad(dy, ar.grad_seg(bias), O)
-            self._grad_done(ctx, bias)
+        wg = layer.weight.requires_grad
+        bg = bias is not None and bias.requires_grad
+        if wg or bg:
+            def param_grads():
+                if wg:
+                    ops.conv_wgrad(x, dy, ar.grad_seg(layer.weight), O, R, S, stride, pad)
+                if bg:
+                    ops.bias_grad(dy, ar.grad_seg(bias), O)
+            self._on_side(ctx, dy.t.device, (x, dy), param_grads)
+            if wg:
+                self._grad_done(ctx, layer.weight)
+            if bg:
+                self._grad_done(ctx, bias)
         if x.needs_grad:
             g, existed = ctx.gbuf(x)
             wt = self.w_t(ctx, layer)
@@ -307,9 +342,11 @@ class Engine(object):
             def bwd():
                 dy = ctx.pop_grad(y)
                 if dy is not None:
-                    dwp = torch.zeros((64, 7, 32), dtype=torch.float32, device=img.device)
-                    ops.conv_wgrad(xa, dy, dwp, 64, 7, 1, 2, 0, cin=32, x_geom=geom)
-                    call("mpn_stem_unpack_wgrad", ops.ptr(dwp), ops.ptr(self.m._arena.grad_seg(w)), 64, ops.stream_ptr())
+                    def stem_wgrad():
+                        dwp = torch.zeros((64, 7, 32), dtype=torch.float32, device=img.device)
+                        ops.conv_wgrad(xa, dy, dwp, 64, 7, 1, 2, 0, cin=32, x_geom=geom)
+                        call("mpn_stem_unpack_wgrad", ops.ptr(dwp), ops.ptr(self.m._arena.grad_seg(w)), 64, ops.stream_ptr())
+                    self._on_side(ctx, dy.t.device, (xa, dy), stem_wgrad)
                 self._grad_done(ctx, w)
             ctx.tape.append(bwd)
         z = self.bn(ctx, y, st, f.bn1, True)
@@ -440,13 +477,19 @@ class Engine(object):
         m = self.m
         ctx.out_grads = out_grads
         m._arena.ensure_grads()
+        dev = m._arena.flat.device
+        side = self.side_stream(dev)
         if m._reducer is not None:
+            m._reducer.launch_stream = side
             m._reducer.begin()
         tape = ctx.tape
         while tape:
             tape.pop()()
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)      # join: parameter gradients are complete
         ctx.grads.clear()
         ctx.keep = []
+        ctx.side_keep = []
         ctx.wt.clear()
         if m._reducer is not None:
             m._reducer.finish()

@@ -70,6 +70,7 @@ class _KernelEvents(object):
 
     def __init__(self):
         self.on = False
+        self.detail = False          # name launches by shape (tools/shape_report.py)
         self.rec = []
 
     def enable(self):
@@ -106,7 +107,8 @@ _ws = {}
 
 def workspace(nbytes, device, slot=0):
     """Persistent scratch (grown geometrically); one buffer per (device, slot)."""
-    key = (str(device), slot)
+    # one buffer per stream as well: launches on different streams must not share (or re-grow) a scratch area
+    key = (str(device), slot, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
@@ -182,7 +184,16 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         # algorithmic FLOPs: 2 * output pixels * Cout * taps * Cin; a stride-s dgrad only has 1/s^2 live taps
         live = (R * S) / float(stride * stride) if mode == 1 else R * S
         flops = 2.0 * x.B * Ho * Wo * Cout * live * min(Cin, x.C if x_geom is None else Cin)
-        KERNEL_EVENTS.end("conv_igemm_kernel<%s,%d,128>" % ("bf16" if dt == torch.bfloat16 else "f32", tc), flops, e0)
+        name = "conv_igemm_kernel<%s,%d,128>" % ("bf16" if dt == torch.bfloat16 else "f32", tc)
+        if KERNEL_EVENTS.detail:
+            es = 2 if dt == torch.bfloat16 else 4
+            byts = x.B * H * W * Cin * es + x.B * Ho * Wo * p.Cout_store * (4 if out_f32 else es) * (2 if accumulate else 1) \
+                + (x.B * Ho * Wo * p.Cout_store * es if res is not None and res_mode == 1 else 0)
+            name = "%s %dx%d %d->%d @%dx%d s%d%s%s%s%s%s|%d" % (
+                "dgrad" if mode == 1 else "fwd", R, S, Cin, Cout, Ho, Wo, stride, " stats" if want_stats else "",
+                " bias" if bias is not None else "", " act%d" % act if act else "", " res%d" % res_mode if res is not None else "",
+                " acc" if accumulate else "", byts)
+        KERNEL_EVENTS.end(name, flops, e0)
     else:
         call("mpn_conv_forward", ctypes.byref(p), stream_ptr())
     return out, stats
@@ -216,8 +227,12 @@ def conv_wgrad(x, dy, dw, Cout, R, S, stride, pad, cin=None, x_geom=None):
     if KERNEL_EVENTS.on:
         e0 = KERNEL_EVENTS.begin()
         call("mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
-        KERNEL_EVENTS.end("conv_wgrad(+reduce)<%s>" % ("bf16" if dt == torch.bfloat16 else "f32"),
-                          2.0 * x.B * dy.H * dy.W * Cout * R * S * Cin, e0)
+        name = "conv_wgrad(+reduce)<%s>" % ("bf16" if dt == torch.bfloat16 else "f32")
+        if KERNEL_EVENTS.detail:
+            es = 2 if dt == torch.bfloat16 else 4
+            name = "wgrad %dx%d %d->%d @%dx%d s%d chunks=%d|%d" % (R, S, Cin, Cout, dy.H, dy.W, stride, chunks,
+                                                                 (x.B * H * W * Cin + x.B * dy.H * dy.W * dy.Cs) * es)
+        KERNEL_EVENTS.end(name, 2.0 * x.B * dy.H * dy.W * Cout * R * S * Cin, e0)
     else:
         call("mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
 
