@@ -233,6 +233,7 @@ def main():
             ev_steps += 1
         loss = step()
         ops.KERNEL_EVENTS.on = False
+    t_enq = time.perf_counter() - t0             # host time to enqueue the K steps (the GPU may still be running)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -270,6 +271,7 @@ def main():
                                    % (args.layers, args.size, args.size, args.batch, args.dtype),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
         }
+        out["host_enqueue_ms_per_step"] = round(t_enq / args.steps * 1000.0, 3)
         gf = GFLOP_PER_IMG_TRAIN.get(("r%d" % args.layers, args.size))
         if gf is not None:
             out["model_tflops_per_gpu"] = round(ips / world * gf / 1000.0, 2)
