@@ -158,13 +158,10 @@ def pmc_traffic(kernel_class):
         return None
     try:
         prof = json.load(open(files[-1]))
-        key = "conv_wgrad_kernel<bf16, 128, 128>" if kernel_class.startswith("conv_wgrad") else kernel_class.replace(",", ", ")
-        best = None
         for k in prof["kernels"]:
-            if k["kernel"].startswith(key.split(">")[0]):
-                if best is None or k["hbm_gb_per_step"] > best["hbm_gb_per_step"]:
-                    best = k
-        return None if best is None else int(best["hbm_bytes_per_launch"])
+            if k["kernel"] == kernel_class:
+                return int(k["hbm_bytes_per_launch"])
+        return None
     except Exception:
         return None
 

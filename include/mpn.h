@@ -77,6 +77,11 @@ typedef struct MpnWgradParams {
 
 int mpn_conv_wgrad_chunks(const MpnWgradParams* p);
 int mpn_conv_wgrad(const MpnWgradParams* p, void* stream);
+/* first stage only (chunks > 1): the per-slice partial gradients go to ws and the caller finishes with
+ * mpn_reduce_partials(ws, chunks, Cout*R*S*Cin, dw, 1, stream) — lets a profiler bracket the MFMA kernel alone */
+int mpn_conv_wgrad_partials(const MpnWgradParams* p, void* stream);
+/* which kernel mpn_conv_wgrad launches for p: (tile_cin << 16) | (tile_cout << 4) | uses_lds_dma */
+int mpn_conv_wgrad_kernel_id(const MpnWgradParams* p);
 
 /* dst[i] (+)= sum_{c<chunks} ws[c*n + i]  — deterministic second stage of split reductions */
 int mpn_reduce_partials(const float* ws, int chunks, int64_t n, float* dst, int accumulate, void* stream);

@@ -61,6 +61,8 @@ SIGNATURES = {
     "mpn_conv_forward": (_i, [_PC, _vp]),
     "mpn_conv_wgrad_chunks": (_i, [_PW]),
     "mpn_conv_wgrad": (_i, [_PW, _vp]),
+    "mpn_conv_wgrad_partials": (_i, [_PW, _vp]),
+    "mpn_conv_wgrad_kernel_id": (_i, [_PW]),
     "mpn_reduce_partials": (_i, [_vp, _i, _i64, _vp, _i, _vp]),
     "mpn_cast_f32_to_bf16": (_i, [_vp, _vp, _i64, _vp]),
     "mpn_weight_transpose": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -117,7 +119,7 @@ SIGNATURES = {
 }
 
 # entry points that return a count, not a status
-_COUNT_FUNCS = {"mpn_conv_stats_tiles", "mpn_conv_tile_rows", "mpn_conv_wgrad_chunks", "mpn_bn_bwd_chunks", "mpn_channel_sum_chunks",
+_COUNT_FUNCS = {"mpn_conv_stats_tiles", "mpn_conv_tile_rows", "mpn_conv_wgrad_chunks", "mpn_conv_wgrad_kernel_id", "mpn_bn_bwd_chunks", "mpn_channel_sum_chunks",
                 "mpn_mse_chunks", "mpn_focal_blocks", "mpn_bce_chunks", "mpn_nms_workspace_bytes", "mpn_version"}
 
 _lib = None

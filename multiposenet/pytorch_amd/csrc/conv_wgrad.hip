@@ -281,170 +281,19 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(const MpnWgradParams
 }
 
 // ------------------------------------------------------------------------------------------------------
-// bf16 128x128 variant built on the CDNA4 LDS transpose read.  Both operands arrive pixel-major ([k][channel]),
-// the MFMA wants 8 consecutive k per lane: instead of re-packing in registers (above), tiles are written to LDS
-// exactly as loaded (one ds_write_b128 per 16 bytes) and fragments are gathered with ds_read_b64_tr_b16, which
-// hands lane i column i of a 4(k) x 16(channel) block.  Rows are 256 B (128 channels); the 16-byte chunk index
-// is XOR-swizzled with f(k) = 2*((k&3) | ((k>>3)&1)<<2) so that the 8 rows a 32-lane half touches in one
-// transpose read cover all 16 chunk slots (64 banks) exactly once, while a row's own 16 chunks stay a
-// permutation of one contiguous 256-byte line (conflict-free writes).
+// bf16 fast path: LDS-DMA + CDNA4 LDS transpose read.  Both operands arrive pixel-major ([k][channel]) while the
+// MFMA wants 8 consecutive k per lane.  Instead of re-packing in registers (generic kernel above), tiles land in
+// LDS exactly as they lie in memory and fragments are gathered with ds_read_b64_tr_b16, which hands lane i column
+// i of a 4(k) x 16(channel) block.  Tiles go HBM -> LDS with `buffer_load_dwordx4 ... lds` (no staging registers,
+// no ds_write pass) into a 3-deep ring, two k-steps ahead of the MFMAs.  The DMA destination is lane-linear
+// (M0 base + lane*16), so the bank swizzle of the tile image is applied on the SOURCE side: the lane that owns LDS
+// slot j of row k fetches channel chunk j ^ swz(k).  Out-of-range lanes (halo taps, channel tail, pixels past the
+// slice) carry an offset beyond num_records and the hardware writes zeros — the dY descriptor is clipped to the
+// slice end, so tail pixels need no per-step mask.  The loads are inline asm, invisible to the compiler's waitcnt
+// bookkeeping: completion is counted by hand (`s_waitcnt vmcnt(n)`, n = one k-step's loads per wave: everything but
+// the newest k-step has landed) and the barrier is the raw s_barrier, so the ring never drains inside the loop.
+// (semantics of the DMA and of the transpose read were pinned with tools/probe_dma.* and tools/probe_tr.*)
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-
-__device__ __forceinline__ int tr_swz(int k) { return 2 * ((k & 3) | (((k >> 3) & 1) << 2)); }
-
-__global__ void __launch_bounds__(256, 3) conv_wgrad_tr_kernel(const MpnWgradParams p, long chunk_pixels) {
-    constexpr int TM = 128, TN = 128, KP = 32;
-    constexpr int TILE_BYTES = KP * 256;                 // one operand tile
-    constexpr int BUF_BYTES = 2 * TILE_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tilesM = (p.Cin + TM - 1) / TM, tilesN = (p.Cout + TN - 1) / TN;
-    const int taps = p.R * p.S;
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = bid % tilesN; bid /= tilesN;
-    const int tm = bid % tilesM; bid /= tilesM;
-    const int tap = bid % taps; bid /= taps;
-    const int chunk = bid;
-    const int r = tap / p.S, s = tap - r * p.S;
-    const int m0 = tm * TM, n0 = tn * TN;
-    const long P = (long)p.B * p.Ho * p.Wo;
-    const long k_begin = (long)chunk * chunk_pixels;
-    long k_end = k_begin + chunk_pixels; if (k_end > P) k_end = P;
-    const bf16_t* __restrict__ X = (const bf16_t*)p.x;
-    const bf16_t* __restrict__ DY = (const bf16_t*)p.dy;
-    const int dy_cs = ((p.Cout + 31) / 32) * 32;
-
-    // load units: (k row, 16-byte chunk) ; 32 rows x 16 chunks = 512 units per operand = 2 per thread
-    int u_k[2], u_c[2], u_lds[2]; bool a_on[2], b_on[2]; PixState a_px[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int u = tid + 256 * q;
-        u_k[q] = u >> 4; u_c[q] = (u & 15) * 8;
-        u_lds[q] = u_k[q] * 256 + (((u & 15) ^ tr_swz(u_k[q])) * 16);
-        a_on[q] = (m0 + u_c[q]) < p.Cin;
-        b_on[q] = (n0 + u_c[q]) < dy_cs;
-        long pix = k_begin + u_k[q]; if (pix >= P) pix = P - 1;
-        a_px[q].init(pix, p.Ho, p.Wo);
-    }
-    f32x4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    u32x4_t ra0[2], rb0[2], ra1[2], rb1[2];
-    const u32x4_t zero4 = (u32x4_t){0u, 0u, 0u, 0u};
-    long k0 = k_begin;
-
-    auto gload = [&](u32x4_t (&ra)[2], u32x4_t (&rb)[2]) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const long pix = k0 + u_k[q];
-            const int hi = a_px[q].ho * p.stride - p.pad + r, wi = a_px[q].wo * p.stride - p.pad + s;
-            const bool ok = a_on[q] && (pix < k_end) && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const long off = (long)a_px[q].b * p.x_sB + (long)hi * p.x_sH + (long)wi * p.x_sW + m0 + u_c[q];
-            ra[q] = ok ? *reinterpret_cast<const u32x4_t*>(X + off) : zero4;
-            a_px[q].advance(KP, p.Ho, p.Wo);
-            const bool okb = b_on[q] && (pix < k_end);
-            rb[q] = okb ? *reinterpret_cast<const u32x4_t*>(DY + pix * p.dy_sP + n0 + u_c[q]) : zero4;
-        }
-        k0 += KP;
-    };
-    auto lstore = [&](int buf, const u32x4_t (&ra)[2], const u32x4_t (&rb)[2]) {
-        unsigned char* la = lds + buf * BUF_BYTES;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            *reinterpret_cast<u32x4_t*>(la + u_lds[q]) = ra[q];
-            *reinterpret_cast<u32x4_t*>(la + TILE_BYTES + u_lds[q]) = rb[q];
-        }
-    };
-    // fragment gather: lane l -> rows k = 8*(l>>4) + 4*h + ((l&15)>>2), 8-byte piece (l&3) of the 16-channel block
-    const int g8 = (lane >> 4) * 8, li = lane & 15;
-    int row_off[2], row_swz[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int k = g8 + 4 * h + (li >> 2);
-        row_off[h] = k * 256;
-        row_swz[h] = tr_swz(k);
-    }
-    const int piece_chunk = (li & 3) >> 1, piece_half = (li & 1) * 8;
-    auto frag = [&](const unsigned char* tile, int c0) -> bf16x8_t {     // c0: first channel of the 16-wide block (multiple of 16)
-        const int lc = (c0 >> 3) + piece_chunk;
-        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4_t*)(tile + row_off[0] + ((lc ^ row_swz[0]) * 16) + piece_half));
-        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4_t*)(tile + row_off[1] + ((lc ^ row_swz[1]) * 16) + piece_half));
-        struct { s16x4_t a, b; } pr = {lo, hi};
-        return __builtin_bit_cast(bf16x8_t, pr);
-    };
-    auto compute = [&](int buf) {
-        const unsigned char* la = lds + buf * BUF_BYTES;
-        const unsigned char* lb = la + TILE_BYTES;
-        bf16x8_t fa[4], fb[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = frag(la, wm * 64 + i * 16);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = frag(lb, wn * 64 + j * 16);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    };
-
-    const long span = k_end - k_begin;
-    const int nsteps = span > 0 ? (int)((span + KP - 1) / KP) : 0;
-    if (nsteps > 0) {
-        gload(ra0, rb0);
-        if (nsteps > 1) gload(ra1, rb1);
-        lstore(0, ra0, rb0);
-    }
-    __syncthreads();
-    int it = 0;
-    for (; it + 1 < nsteps; it += 2) {
-        if (it + 2 < nsteps) gload(ra0, rb0);
-        compute(0);
-        lstore(1, ra1, rb1);
-        __syncthreads();
-        if (it + 3 < nsteps) gload(ra1, rb1);
-        compute(1);
-        if (it + 2 < nsteps) lstore(0, ra0, rb0);
-        __syncthreads();
-    }
-    if (it < nsteps) compute(0);
-
-    const long NW = (long)p.Cout * taps * p.Cin;
-    float* __restrict__ dst = (p.chunks > 1) ? (p.ws + (long)chunk * NW) : p.dw;
-    const bool add = (p.chunks == 1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int cin = m0 + wm * 64 + i * 16 + (lane >> 4) * 4;
-        if (cin >= p.Cin) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int cout = n0 + wn * 64 + j * 16 + (lane & 15);
-            if (cout >= p.Cout) continue;
-            float* q = dst + ((long)cout * taps + tap) * p.Cin + cin;
-            float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            if (add) {
-                const float4 o = *reinterpret_cast<const float4*>(q);
-                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-            }
-            *reinterpret_cast<float4*>(q) = v;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// LDS-DMA variant of the transpose-read kernel (the default bf16 128x128 path).  Operand tiles go HBM -> LDS with
-// `buffer_load_dwordx4 ... lds` (no staging registers, no ds_write pass) into a 3-deep ring, two k-steps ahead of
-// the MFMAs.  The DMA destination is lane-linear (M0 base + lane*16), so the chunk swizzle of the tile image is
-// applied on the SOURCE side: the lane that owns LDS slot j of row k fetches channel chunk j ^ tr_swz(k).
-// Out-of-range lanes (halo taps, channel tail, pixels past the slice) carry an offset beyond num_records and the
-// hardware writes zeros — the dY descriptor is clipped to the slice end, so tail pixels need no per-step mask.
-// The loads are inline asm, invisible to the compiler's waitcnt bookkeeping: completion is counted by hand
-// (`s_waitcnt vmcnt(4)` = everything but the newest k-step's four loads has landed) and the barrier is the raw
-// s_barrier, so the ring never drains inside the loop.
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ i32x4_t make_rsrc(const void* base, unsigned bytes) {
@@ -465,11 +314,26 @@ __device__ __forceinline__ void lds_dma16(unsigned voff, i32x4_t rsrc, unsigned 
 
 constexpr unsigned DMA_OOB = 0x80000000u;     // tensors are < 2 GB (launcher check): marker + soffset never wraps
 
-template <int NST>
-__global__ void __launch_bounds__(256, NST == 3 ? 3 : 2) conv_wgrad_dma_kernel(const MpnWgradParams p, long chunk_pixels) {
-    constexpr int TM = 128, TN = 128, KP = 32;
-    constexpr int TILE_BYTES = KP * 256;                 // one operand tile
-    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+// Tile image in LDS: 32 pixel rows of ROWB = tile_channels * 2 bytes, back to back.  ds_read_b64_tr_b16 is serviced in
+// two 32-lane halves; one half touches 8 rows (k = {0..3} + 8*{0,1} + 4h) x 32 bytes, which must land on 8 distinct
+// 32-byte bank slots of the 256-byte bank row.  256-byte rows: every row starts on slot 0, so the 32-byte piece index
+// is XORed with (k&3)|((k>>3)&1)<<2.  128-byte rows: rows k and k+1 already differ by 4 slots, the remaining four
+// rows of equal parity are separated by XORing the piece index with ((k>>1)&1)|((k>>3)&1)<<1.  Swizzles are in
+// 16-byte chunk units (piece << 1) and are applied on the DMA source side.
+template <int ROWB> __device__ __forceinline__ int dma_swz(int k) {
+    return ROWB == 256 ? 2 * ((k & 3) | (((k >> 3) & 1) << 2)) : 2 * (((k >> 1) & 1) | (((k >> 3) & 1) << 1));
+}
+
+template <int TM, int TN>
+__global__ void __launch_bounds__(256, 3) conv_wgrad_dma_kernel(const MpnWgradParams p, long chunk_pixels) {
+    constexpr int KP = 32, NST = 3;
+    constexpr int ROWA = TM * 2, ROWB = TN * 2;              // bytes per pixel row of each tile
+    constexpr int A_BYTES = KP * ROWA, B_BYTES = KP * ROWB;
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int QA = A_BYTES / 4096, QB = B_BYTES / 4096;  // DMA instructions (1 KiB each) per wave per k-step
+    constexpr int RPA = 1024 / ROWA, RPB = 1024 / ROWB;      // tile rows covered by one instruction
+    constexpr int MM = TM / 32, MN = TN / 32;                // 16x16 fragments per wave (2 x 2 waves)
+    static_assert((TM == 128 || TM == 64) && (TN == 128 || TN == 64), "tiles are 64 or 128 channels wide");
     __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -490,75 +354,84 @@ __global__ void __launch_bounds__(256, NST == 3 ? 3 : 2) conv_wgrad_dma_kernel(c
     const i32x4_t rsrc_x = make_rsrc(p.x, (unsigned)((long)p.B * p.x_sB * 2));
     const i32x4_t rsrc_dy = make_rsrc(p.dy, (unsigned)((k_end > k_begin ? k_end : 0) * (long)p.dy_sP * 2));
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    const unsigned wave_rows = (unsigned)__builtin_amdgcn_readfirstlane(wave) * 8u;
+    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
 
-    // DMA units: instruction q of wave w fills rows 8w+4q .. 8w+4q+3 of a tile (1 KiB); lane -> row (lane>>4), slot (lane&15)
-    unsigned b_voff[2]; int a_chan[2]; bool a_on[2]; PixState a_px[2];
+    // DMA units: instruction q of wave w fills rows (w*Q + q)*RP .. +RP-1 of a tile; lane -> row (lane / chunks-per-row),
+    // slot (lane % chunks-per-row); the slot's source chunk is slot ^ swz(row)
+    unsigned b_voff[QB]; int a_chan[QA]; bool a_on[QA]; PixState a_px[QA];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int row = (int)wave_rows + 4 * q + (lane >> 4);
-        const int chan = (((lane & 15) ^ tr_swz(row)) * 8);
+    for (int q = 0; q < QA; ++q) {
+        const int row = ((int)wave_u * QA + q) * RPA + lane / (ROWA / 16);
+        const int chan = ((lane % (ROWA / 16)) ^ dma_swz<ROWA>(row)) * 8;
         a_chan[q] = m0 + chan;
         a_on[q] = (m0 + chan) < p.Cin;
         long pix = k_begin + row; if (pix >= P) pix = P - 1;     // beyond-the-end rows meet zero dY rows
         a_px[q].init(pix, p.Ho, p.Wo);
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        const int row = ((int)wave_u * QB + q) * RPB + lane / (ROWB / 16);
+        const int chan = ((lane % (ROWB / 16)) ^ dma_swz<ROWB>(row)) * 8;
         b_voff[q] = ((n0 + chan) < dy_cs) ? (unsigned)(((k_begin + row) * (long)p.dy_sP + n0 + chan) * 2) : DMA_OOB;
     }
     const unsigned b_step = (unsigned)(KP * p.dy_sP * 2);
     unsigned b_soff = 0;
     const int adv_t = KP / p.Wo, adv_w = KP - adv_t * p.Wo, adv_b = adv_t / p.Ho, adv_h = adv_t - adv_b * p.Ho;
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[MM][MN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    auto issue = [&](unsigned stage) {       // queue one k-step (4 DMA instructions per wave) into ring slot `stage`
-        const unsigned st = lds_base + stage * STAGE_BYTES + wave_rows * 256u;
+    auto issue = [&](unsigned stage) {       // queue one k-step (QA + QB DMA instructions per wave) into ring slot `stage`
+        const unsigned st = lds_base + stage * STAGE_BYTES;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < QA; ++q) {
             const int hi = a_px[q].ho * p.stride - p.pad + r, wi = a_px[q].wo * p.stride - p.pad + s;
             const bool ok = a_on[q] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             const unsigned off = ((unsigned)a_px[q].b * (unsigned)p.x_sB + (unsigned)hi * (unsigned)p.x_sH +
                                   (unsigned)wi * (unsigned)p.x_sW + (unsigned)a_chan[q]) * 2u;
-            lds_dma16(ok ? off : DMA_OOB, rsrc_x, 0u, __builtin_amdgcn_readfirstlane(st + q * 1024u));
+            lds_dma16(ok ? off : DMA_OOB, rsrc_x, 0u, __builtin_amdgcn_readfirstlane(st + (wave_u * QA + q) * 1024u));
             a_px[q].advance_digits(adv_b, adv_h, adv_w, p.Ho, p.Wo);
-            lds_dma16(b_voff[q], rsrc_dy, b_soff, __builtin_amdgcn_readfirstlane(st + TILE_BYTES + q * 1024u));
         }
+#pragma unroll
+        for (int q = 0; q < QB; ++q)
+            lds_dma16(b_voff[q], rsrc_dy, b_soff, __builtin_amdgcn_readfirstlane(st + A_BYTES + (wave_u * QB + q) * 1024u));
         b_soff += b_step;
     };
 
+    // fragment gather: lane l -> rows k = 8*(l>>4) + 4*h + ((l&15)>>2), 8-byte piece (l&3) of the 16-channel block
     const int g8 = (lane >> 4) * 8, li = lane & 15;
-    int row_off[2], row_swz[2];
+    const int piece_chunk = (li & 3) >> 1, piece_half = (li & 1) * 8;
+    int a_row[2], a_swz[2], b_row[2], b_swz[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int k = g8 + 4 * h + (li >> 2);
-        row_off[h] = k * 256;
-        row_swz[h] = tr_swz(k);
+        a_row[h] = k * ROWA; a_swz[h] = dma_swz<ROWA>(k);
+        b_row[h] = k * ROWB; b_swz[h] = dma_swz<ROWB>(k);
     }
-    const int piece_chunk = (li & 3) >> 1, piece_half = (li & 1) * 8;
-    auto frag = [&](const unsigned char* tile, int c0) -> bf16x8_t {
-        const int lc = (c0 >> 3) + piece_chunk;
+    auto frag = [&](const unsigned char* tile, const int (&row)[2], const int (&swz)[2], int c0) -> bf16x8_t {
+        const int lc = (c0 >> 3) + piece_chunk;          // c0: first channel of the 16-wide block (multiple of 16)
         s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4_t*)(tile + row_off[0] + ((lc ^ row_swz[0]) * 16) + piece_half));
+            (__attribute__((address_space(3))) s16x4_t*)(tile + row[0] + ((lc ^ swz[0]) * 16) + piece_half));
         s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4_t*)(tile + row_off[1] + ((lc ^ row_swz[1]) * 16) + piece_half));
+            (__attribute__((address_space(3))) s16x4_t*)(tile + row[1] + ((lc ^ swz[1]) * 16) + piece_half));
         struct { s16x4_t a, b; } pr = {lo, hi};
         return __builtin_bit_cast(bf16x8_t, pr);
     };
     auto compute = [&](unsigned stage) {
         const unsigned char* la = lds + stage * STAGE_BYTES;
-        const unsigned char* lb = la + TILE_BYTES;
-        bf16x8_t fa[4], fb[4];
+        const unsigned char* lb = la + A_BYTES;
+        bf16x8_t fa[MM], fb[MN];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = frag(la, wm * 64 + i * 16);
+        for (int i = 0; i < MM; ++i) fa[i] = frag(la, a_row, a_swz, wm * (TM / 2) + i * 16);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = frag(lb, wn * 64 + j * 16);
+        for (int j = 0; j < MN; ++j) fb[j] = frag(lb, b_row, b_swz, wn * (TN / 2) + j * 16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MM; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < MN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     };
 
@@ -566,11 +439,11 @@ __global__ void __launch_bounds__(256, NST == 3 ? 3 : 2) conv_wgrad_dma_kernel(c
     const int nsteps = span > 0 ? (int)((span + KP - 1) / KP) : 0;
     // steps past the slice end are still queued (their dY rows are out of range -> zeros, never consumed) so the
     // outstanding-load count is the same in every iteration
-#pragma unroll
-    for (int q = 0; q < NST - 1; ++q) issue((unsigned)q);
-    unsigned cur = 0u, nxt = NST - 1;
+    issue(0u);
+    issue(1u);
+    unsigned cur = 0u, nxt = 2u;
     for (int it = 0; it < nsteps; ++it) {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (NST - 2)) : "memory");      // k-step `it` has landed (this wave's part)
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(QA + QB) : "memory");      // k-step `it` has landed (this wave's part)
         __builtin_amdgcn_s_barrier();                          // ... everyone's part; and slot `nxt` is no longer being read
         issue(nxt);
         compute(cur);
@@ -583,12 +456,12 @@ __global__ void __launch_bounds__(256, NST == 3 ? 3 : 2) conv_wgrad_dma_kernel(c
     float* __restrict__ dst = (p.chunks > 1) ? (p.ws + (long)chunk * NW) : p.dw;
     const bool add = (p.chunks == 1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int cin = m0 + wm * 64 + i * 16 + (lane >> 4) * 4;
+    for (int i = 0; i < MM; ++i) {
+        const int cin = m0 + wm * (TM / 2) + i * 16 + (lane >> 4) * 4;
         if (cin >= p.Cin) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int cout = n0 + wn * 64 + j * 16 + (lane & 15);
+        for (int j = 0; j < MN; ++j) {
+            const int cout = n0 + wn * (TN / 2) + j * 16 + (lane & 15);
             if (cout >= p.Cout) continue;
             float* q = dst + ((long)cout * taps + tap) * p.Cin + cin;
             float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
@@ -648,9 +521,24 @@ int launch_wgrad_n(const MpnWgradParams& p, int tn, long grid, long chunk_pixels
     return mpn_launch_status();
 }
 
+// bf16 launches whose tensors fit 32-bit buffer offsets take the LDS-DMA kernel (tiles of 64 or 128 channels; narrower
+// operands ride in a zero-filled 64-wide tile); everything else (f32 parity path, > 2 GB tensors) the generic kernel.
+inline bool wgrad_uses_dma(const MpnWgradParams& p) {
+    static const bool use_dma = !(getenv("MPN_WGRAD_NO_DMA") && atoi(getenv("MPN_WGRAD_NO_DMA")));
+    const long P = (long)p.B * p.Ho * p.Wo;
+    const bool small = (long)p.B * p.x_sB * 2 < 0x7fffffffL && P * p.dy_sP * 2 < 0x7fffffffL;
+    return p.dtype == MPN_BF16 && use_dma && small && p.Cin % 8 == 0;
+}
+
+inline void wgrad_tiles(const MpnWgradParams& p, int& tm, int& tn) {
+    tm = pick_tile(p.Cin); tn = pick_tile(p.Cout);
+    if (wgrad_uses_dma(p)) { if (tm < 64) tm = 64; if (tn < 64) tn = 64; }
+}
+
 template <typename T>
-int launch_wgrad(const MpnWgradParams& p, hipStream_t st) {
-    const int tm = pick_tile(p.Cin), tn = pick_tile(p.Cout);
+int launch_wgrad(const MpnWgradParams& p, hipStream_t st, bool reduce = true) {
+    int tm, tn;
+    wgrad_tiles(p, tm, tn);
     const long tilesM = (p.Cin + tm - 1) / tm, tilesN = (p.Cout + tn - 1) / tn;
     const long P = (long)p.B * p.Ho * p.Wo;
     const int kp = sizeof(T) == 2 ? 32 : 16;
@@ -659,28 +547,21 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st) {
     const long grid = tilesM * tilesN * p.R * p.S * p.chunks;
     if (grid <= 0 || grid > 0x7fffffffL || P >= 0x7fffffffL) return MPN_E_BADARG;
     int rc;
-    static const bool use_tr = !(getenv("MPN_WGRAD_NO_TR") && atoi(getenv("MPN_WGRAD_NO_TR")));
-    static const bool use_dma = !(getenv("MPN_WGRAD_NO_DMA") && atoi(getenv("MPN_WGRAD_NO_DMA")));
-    const bool small = (long)p.B * p.x_sB * 2 < 0x7fffffffL && P * p.dy_sP * 2 < 0x7fffffffL;      // 32-bit buffer offsets
-    if (sizeof(T) == 2 && tm == 128 && tn == 128 && use_tr && p.Cin % 8 == 0) {
-        static const int nst_env = getenv("MPN_WGRAD_NST") ? atoi(getenv("MPN_WGRAD_NST")) : 0;
-        // a launch that leaves each CU with ~2 workgroups affords a deeper ring (more k-steps of DMA in flight)
-        const int nst = nst_env ? nst_env : 3;       // deeper rings measured no faster (the loop is not DMA-latency-bound)
-        if (use_dma && small) {
-            if (nst == 5) hipLaunchKernelGGL(conv_wgrad_dma_kernel<5>, dim3((unsigned)grid), dim3(256), 0, st, p, chunk_pixels);
-            else if (nst == 4) hipLaunchKernelGGL(conv_wgrad_dma_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, p, chunk_pixels);
-            else hipLaunchKernelGGL(conv_wgrad_dma_kernel<3>, dim3((unsigned)grid), dim3(256), 0, st, p, chunk_pixels);
-        }
-        else hipLaunchKernelGGL(conv_wgrad_tr_kernel, dim3((unsigned)grid), dim3(256), 0, st, p, chunk_pixels);
+    const dim3 g((unsigned)grid), blk(256);
+    if (sizeof(T) == 2 && wgrad_uses_dma(p)) {
+        if (tm == 128 && tn == 128) hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 128>), g, blk, 0, st, p, chunk_pixels);
+        else if (tm == 128) hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 64>), g, blk, 0, st, p, chunk_pixels);
+        else if (tn == 128) hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 128>), g, blk, 0, st, p, chunk_pixels);
+        else hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 64>), g, blk, 0, st, p, chunk_pixels);
         rc = mpn_launch_status();
     } else if (tm == 128) rc = launch_wgrad_n<T, 128>(p, tn, grid, chunk_pixels, st);
     else if (tm == 64) rc = launch_wgrad_n<T, 64>(p, tn, grid, chunk_pixels, st);
     else rc = launch_wgrad_n<T, 32>(p, tn, grid, chunk_pixels, st);
     if (rc != 0) return rc;
-    if (p.chunks > 1) {
+    if (p.chunks > 1 && reduce) {
         const long n = (long)p.Cout * p.R * p.S * p.Cin;
         const long threads = (n + 3) / 4;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(reduce_partials_kernel, g.x ? dim3((unsigned)((threads + 255) / 256)) : dim3(1), dim3(256), 0, st,
                            (const float*)p.ws, p.chunks, n, p.dw, 1);
         rc = mpn_launch_status();
     }
@@ -691,7 +572,8 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st) {
 
 extern "C" int mpn_conv_wgrad_chunks(const MpnWgradParams* p) {
     if (!p) return MPN_E_BADARG;
-    const int tm = pick_tile(p->Cin), tn = pick_tile(p->Cout);
+    int tm, tn;
+    wgrad_tiles(*p, tm, tn);
     const long tiles = (long)((p->Cin + tm - 1) / tm) * ((p->Cout + tn - 1) / tn) * p->R * p->S;
     const long P = (long)p->B * p->Ho * p->Wo;
     static const long target = getenv("MPN_WGRAD_TARGET") ? atol(getenv("MPN_WGRAD_TARGET")) : 512;
@@ -715,6 +597,24 @@ extern "C" int mpn_conv_wgrad(const MpnWgradParams* pp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (p.dtype == MPN_F32) return launch_wgrad<float>(p, st);
     return launch_wgrad<bf16_t>(p, st);
+}
+
+extern "C" int mpn_conv_wgrad_partials(const MpnWgradParams* pp, void* stream) {
+    if (!pp) return MPN_E_BADARG;
+    const MpnWgradParams& p = *pp;
+    MPN_CHECK_ARG(p.x && p.dy && p.dw && p.ws && p.chunks > 1);
+    MPN_CHECK_ARG(p.dtype == MPN_F32 || p.dtype == MPN_BF16);
+    MPN_CHECK_ARG(p.B > 0 && p.Ho > 0 && p.Wo > 0 && p.Cin > 0 && p.Cout > 0 && p.Cin % 8 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (p.dtype == MPN_F32) return launch_wgrad<float>(p, st, false);
+    return launch_wgrad<bf16_t>(p, st, false);
+}
+
+extern "C" int mpn_conv_wgrad_kernel_id(const MpnWgradParams* p) {
+    if (!p) return MPN_E_BADARG;
+    int tm, tn;
+    wgrad_tiles(*p, tm, tn);
+    return (tm << 16) | (tn << 4) | (wgrad_uses_dma(*p) ? 1 : 0);
 }
 
 extern "C" int mpn_reduce_partials(const float* ws, int chunks, int64_t n, float* dst, int accumulate, void* stream) {

@@ -184,7 +184,10 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         # algorithmic FLOPs: 2 * output pixels * Cout * taps * Cin; a stride-s dgrad only has 1/s^2 live taps
         live = (R * S) / float(stride * stride) if mode == 1 else R * S
         flops = 2.0 * x.B * Ho * Wo * Cout * live * min(Cin, x.C if x_geom is None else Cin)
-        name = "conv_igemm_kernel<%s,%d,128>" % ("bf16" if dt == torch.bfloat16 else "f32", tc)
+        # the name rocprofv3 prints for this instantiation (tools/rocprof_summary.py spelling)
+        general = (scale is not None or bias is not None or res is not None or accumulate or act != 0 or Cout % tc != 0)
+        name = "conv_igemm_kernel<%s, %d, 128, %s, %s>" % ("bf16" if dt == torch.bfloat16 else "float", tc,
+                                                          "true" if p.out_f32 else "false", "true" if general else "false")
         if KERNEL_EVENTS.detail:
             es = 2 if dt == torch.bfloat16 else 4
             byts = x.B * H * W * Cin * es + x.B * Ho * Wo * p.Cout_store * (4 if out_f32 else es) * (2 if accumulate else 1) \
@@ -225,14 +228,21 @@ def conv_wgrad(x, dy, dw, Cout, R, S, stride, pad, cin=None, x_geom=None):
         ws = workspace(chunks * Cout * R * S * Cin * 4, dev, slot=1)
         p.ws = ws.data_ptr()
     if KERNEL_EVENTS.on:
+        # bracket the MFMA kernel alone (the partial-sum reduction is launched separately) so the class time
+        # matches the kernel's own row in a rocprofv3 trace
+        kid = call("mpn_conv_wgrad_kernel_id", ctypes.byref(p))
         e0 = KERNEL_EVENTS.begin()
-        call("mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
-        name = "conv_wgrad(+reduce)<%s>" % ("bf16" if dt == torch.bfloat16 else "f32")
+        call("mpn_conv_wgrad_partials" if chunks > 1 else "mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
+        dts = "bf16" if dt == torch.bfloat16 else "float"
+        name = ("conv_wgrad_dma_kernel<%d, %d>" % (kid >> 16, (kid >> 4) & 0xfff) if (kid & 1)
+                else "conv_wgrad_kernel<%s, %d, %d>" % (dts, kid >> 16, (kid >> 4) & 0xfff))
         if KERNEL_EVENTS.detail:
             es = 2 if dt == torch.bfloat16 else 4
             name = "wgrad %dx%d %d->%d @%dx%d s%d chunks=%d|%d" % (R, S, Cin, Cout, dy.H, dy.W, stride, chunks,
                                                                  (x.B * H * W * Cin + x.B * dy.H * dy.W * dy.Cs) * es)
         KERNEL_EVENTS.end(name, 2.0 * x.B * dy.H * dy.W * Cout * R * S * Cin, e0)
+        if chunks > 1:
+            call("mpn_reduce_partials", p.ws, chunks, Cout * R * S * Cin, p.dw, 1, stream_ptr())
     else:
         call("mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
 
