@@ -442,9 +442,11 @@ constexpr int kTP = 128;
 inline int pick_tc(int cout_store, long tilesP) {
     if (cout_store <= 32) return 32;
     if (cout_store <= 64) return 64;
-    // 128-row tiles unless that leaves the 256 CUs with fewer than ~3 workgroups each
+    // 128-row tiles unless that leaves most of the 256 CUs empty (measured: 450 workgroups of 128x128 beat 900 of 64x128,
+    // the larger tile moves a third less data per FLOP through the DMA/LDS path that bounds the loop)
     const long blocks128 = tilesP * ((cout_store + 127) / 128);
-    return blocks128 >= 768 ? 128 : 64;
+    static const long min_blocks = getenv("MPN_TC_MIN_BLOCKS") ? atol(getenv("MPN_TC_MIN_BLOCKS")) : 200;
+    return blocks128 >= min_blocks ? 128 : 64;
 }
 
 template <typename T, bool OUTF32, bool GENERAL>
