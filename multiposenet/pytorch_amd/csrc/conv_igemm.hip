@@ -305,7 +305,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // are invisible to the compiler's waitcnt pass: completion is counted by hand (vmcnt(LPS) = everything but the
 // newest k-step has landed) and the barrier is the raw s_barrier, so the ring never drains inside the loop.
 template <typename T, int TC, int TP, bool OUTF32, bool GENERAL>
-__global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams p, const int dbg) {
+__global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_kernel(const MpnConvParams p, const int dbg) {
     using C = ConvCfg<T, TC, TP>;
     __shared__ __attribute__((aligned(16))) unsigned char lds[C::NST * C::STAGE_BYTES];
 
@@ -439,19 +439,26 @@ __global__ void __launch_bounds__(256, 3) conv_igemm_kernel(const MpnConvParams 
 
 constexpr int kTP = 128;
 
-inline int pick_tc(int cout_store, long tilesP) {
+// Block tile height (output channels).  The k-loop is bound by the DMA/LDS path, so the tallest tile that still
+// fills the chip wins: 256 rows (2 workgroups per CU) for long contractions with enough workgroups, else 128 rows
+// down to ~200 workgroups (measured: 450 x 128x128 beats 900 x 64x128 at 30x30), else 64.
+inline int pick_tc(const MpnConvParams& p, long tilesP) {
+    const int cout_store = p.Cout_store;
     if (cout_store <= 32) return 32;
     if (cout_store <= 64) return 64;
-    // 128-row tiles unless that leaves most of the 256 CUs empty (measured: 450 workgroups of 128x128 beat 900 of 64x128,
-    // the larger tile moves a third less data per FLOP through the DMA/LDS path that bounds the loop)
-    const long blocks128 = tilesP * ((cout_store + 127) / 128);
     static const long min_blocks = getenv("MPN_TC_MIN_BLOCKS") ? atol(getenv("MPN_TC_MIN_BLOCKS")) : 200;
+    static const long min_blocks256 = getenv("MPN_TC256_MIN_BLOCKS") ? atol(getenv("MPN_TC256_MIN_BLOCKS")) : 400;
+    static const long min_ksteps256 = getenv("MPN_TC256_MIN_KSTEPS") ? atol(getenv("MPN_TC256_MIN_KSTEPS")) : 16;
+    const long ksteps = (long)p.R * p.S * p.Cin / (p.dtype == MPN_F32 ? 16 : 32);
+    if (cout_store >= 256 && tilesP * ((cout_store + 255) / 256) >= min_blocks256 && ksteps >= min_ksteps256) return 256;
+    const long blocks128 = tilesP * ((cout_store + 127) / 128);
     return blocks128 >= min_blocks ? 128 : 64;
 }
 
 template <typename T, bool OUTF32, bool GENERAL>
 int launch_conv_k(const MpnConvParams& p, int tc, long grid, int dbg, hipStream_t st) {
-    if (tc == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+    if (tc == 256) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+    else if (tc == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
     else if (tc == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
     else hipLaunchKernelGGL((conv_igemm_kernel<T, 32, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
     return mpn_launch_status();
@@ -461,7 +468,7 @@ template <typename T, bool OUTF32>
 int launch_conv(const MpnConvParams& p, hipStream_t st) {
     const long P = (long)p.B * p.Ho * p.Wo;
     const long tilesP = (P + kTP - 1) / kTP;
-    const int tc = pick_tc(p.Cout_store, tilesP);
+    const int tc = pick_tc(p, tilesP);
     const long tilesC = (p.Cout_store + tc - 1) / tc;
     const long grid = tilesP * tilesC;
     if (grid <= 0 || grid > 0x7fffffffL || P >= 0x7fffffffL) return MPN_E_BADARG;
@@ -482,7 +489,7 @@ extern "C" int mpn_conv_stats_tiles(const MpnConvParams* p) {
 extern "C" int mpn_conv_tile_rows(const MpnConvParams* p) {
     if (!p) return MPN_E_BADARG;
     const long P = (long)p->B * p->Ho * p->Wo;
-    return pick_tc(p->Cout_store, (P + kTP - 1) / kTP);
+    return pick_tc(*p, (P + kTP - 1) / kTP);
 }
 
 extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
