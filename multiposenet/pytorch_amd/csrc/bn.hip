@@ -49,7 +49,7 @@ __global__ void bn_finalize_train_kernel(const float* __restrict__ stats, int ti
                                          float* __restrict__ rm, float* __restrict__ rv, float momentum, float eps,
                                          float* __restrict__ mean, float* __restrict__ invstd,
                                          float* __restrict__ scale, float* __restrict__ shift) {
-    __shared__ double sh[2][64][5];
+    __shared__ double sh[2][4][4];
     const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
     const int c = blockIdx.x * 4 + cl;
     double s1 = 0.0, s2 = 0.0;
@@ -59,11 +59,15 @@ __global__ void bn_finalize_train_kernel(const float* __restrict__ stats, int ti
             s1 += (double)v.x; s2 += (double)v.y;
         }
     }
-    sh[0][sl][cl] = s1; sh[1][sl][cl] = s2;
+    // the 16 slices a wave holds for each channel: xor-butterfly over lane bits 2..5, then 4 wave partials through LDS
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 4) { sh[0][wave][cl] = s1; sh[1][wave][cl] = s2; }
     __syncthreads();
     if (sl == 0 && c < C) {
-        s1 = 0.0; s2 = 0.0;
-        for (int k = 0; k < 64; ++k) { s1 += sh[0][k][cl]; s2 += sh[1][k][cl]; }
+        s1 = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
+        s2 = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
         const double mu = s1 / count;
         double var = s2 / count - mu * mu;
         if (var < 0.0) var = 0.0;
@@ -173,7 +177,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
                                        int train, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
-    __shared__ double sh[2][64][5];
+    __shared__ double sh[2][4][4];
     const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
     const int c = blockIdx.x * 4 + cl;
     double s1 = 0.0, s2 = 0.0;
@@ -183,11 +187,14 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int ch
             s1 += (double)v.x; s2 += (double)v.y;
         }
     }
-    sh[0][sl][cl] = s1; sh[1][sl][cl] = s2;
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 4) { sh[0][wave][cl] = s1; sh[1][wave][cl] = s2; }
     __syncthreads();
     if (sl == 0 && c < C) {
-        s1 = 0.0; s2 = 0.0;
-        for (int k = 0; k < 64; ++k) { s1 += sh[0][k][cl]; s2 += sh[1][k][cl]; }
+        s1 = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
+        s2 = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
         if (dbeta) dbeta[c] += (float)s1;
         if (dgamma) dgamma[c] += (float)s2;
         if (coef) {

@@ -474,6 +474,8 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_dma_kernel(const MpnWgradPa
     }
 }
 
+// dst[i] (+)= sum_c ws[c][i], chunks added in index order (deterministic).  (A variant that split the chunks over four
+// slice-groups per column with an LDS combine measured slower: 23 vs 13 us on the layer3 shapes.)
 __global__ void reduce_partials_kernel(const float* __restrict__ ws, int chunks, long n, float* __restrict__ dst, int accumulate) {
     const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= n) return;
@@ -491,6 +493,11 @@ __global__ void reduce_partials_kernel(const float* __restrict__ ws, int chunks,
             dst[i] = a;
         }
     }
+}
+
+inline int launch_reduce_partials(const float* ws, int chunks, long n, float* dst, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0, st, ws, chunks, n, dst, accumulate);
+    return mpn_launch_status();
 }
 
 // small n (bias gradients: n = channels, many chunks): 16 outputs x 16 chunk-slices per block
@@ -559,11 +566,7 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st, bool reduce = true) {
     else rc = launch_wgrad_n<T, 32>(p, tn, grid, chunk_pixels, st);
     if (rc != 0) return rc;
     if (p.chunks > 1 && reduce) {
-        const long n = (long)p.Cout * p.R * p.S * p.Cin;
-        const long threads = (n + 3) / 4;
-        hipLaunchKernelGGL(reduce_partials_kernel, g.x ? dim3((unsigned)((threads + 255) / 256)) : dim3(1), dim3(256), 0, st,
-                           (const float*)p.ws, p.chunks, n, p.dw, 1);
-        rc = mpn_launch_status();
+        rc = launch_reduce_partials((const float*)p.ws, p.chunks, (long)p.Cout * p.R * p.S * p.Cin, p.dw, 1, st);
     }
     return rc;
 }
@@ -624,8 +627,5 @@ extern "C" int mpn_reduce_partials(const float* ws, int chunks, int64_t n, float
                            ws, chunks, (long)n, dst, accumulate);
         return mpn_launch_status();
     }
-    const long threads = (n + 3) / 4;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       ws, chunks, (long)n, dst, accumulate);
-    return mpn_launch_status();
+    return launch_reduce_partials(ws, chunks, (long)n, dst, accumulate, (hipStream_t)stream);
 }
