@@ -93,6 +93,10 @@ int mpn_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* Wt[ci][r][s][co_pad] = W[co][r][s][ci] (co >= Cout -> 0); ci_pad rows beyond Cin are zero too */
 int mpn_weight_transpose(const float* w, void* wt, int Cout, int RS, int Cin, int Cout_pad,
                          int dtype, void* stream);
+/* all layers at once.  table[l] = {src offset in `arena` (floats), dst offset in `dst` (elements), Cout, RS, Cin, Cout_pad,
+ * first block of the layer, ceil(Cin/32)} as int64; nblocks = sum over layers of ceil(Cin/32)*ceil(Cout_pad/32)*RS */
+int mpn_weight_transpose_batched(const float* arena, void* dst, const int64_t* table, int nlayers, int64_t nblocks,
+                                 int dtype, void* stream);
 /* copy f32 [Cout][K] -> dtype [Cout][Kpad] zero padded (used for narrow-Cin / linear layers) */
 int mpn_weight_pad_k(const float* w, void* dst, int Cout, int K, int Kpad, int dtype, void* stream);
 /* stem 7x7x3: W[64][7][7][3] f32 <-> packed [64][7][32] (slot s*4+c, c<3, s<7; rest zero) */

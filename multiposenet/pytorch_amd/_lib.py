@@ -66,6 +66,7 @@ SIGNATURES = {
     "mpn_reduce_partials": (_i, [_vp, _i, _i64, _vp, _i, _vp]),
     "mpn_cast_f32_to_bf16": (_i, [_vp, _vp, _i64, _vp]),
     "mpn_weight_transpose": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mpn_weight_transpose_batched": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp]),
     "mpn_weight_pad_k": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "mpn_stem_pack_weight": (_i, [_vp, _vp, _i, _i, _vp]),
     "mpn_stem_unpack_wgrad": (_i, [_vp, _vp, _i, _vp]),

@@ -48,6 +48,40 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, T* __restri
     }
 }
 
+// every layer's dgrad operand in one launch: table row l = {src offset (floats), dst offset (elements), Cout, RS, Cin,
+// Cout_pad, first block, blocks along Cin}; block -> layer by binary search over the first-block column
+template <typename T>
+__global__ void weight_transpose_batched_kernel(const float* __restrict__ arena, T* __restrict__ dst, const long* __restrict__ table, int nlayers) {
+    __shared__ float tile[32][33];
+    const long b = blockIdx.x;
+    int lo = 0, hi = nlayers - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 8 + 6] <= b) lo = mid; else hi = mid - 1;
+    }
+    const long* row = table + lo * 8;
+    const float* __restrict__ w = arena + row[0];
+    T* __restrict__ wt = dst + row[1];
+    const int Cout = (int)row[2], RS = (int)row[3], Cin = (int)row[4], Cout_pad = (int)row[5], gx = (int)row[7];
+    const int gy = (Cout_pad + 31) / 32;
+    long lb = b - row[6];
+    const int bx = (int)(lb % gx); lb /= gx;
+    const int by = (int)(lb % gy); lb /= gy;
+    const int rs = (int)lb;
+    const int ci0 = bx * 32, co0 = by * 32;
+    for (int k = threadIdx.y; k < 32; k += 8) {
+        const int co = co0 + k, ci = ci0 + threadIdx.x;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) v = w[((long)co * RS + rs) * Cin + ci];
+        tile[k][threadIdx.x] = v;
+    }
+    __syncthreads();
+    for (int k = threadIdx.y; k < 32; k += 8) {
+        const int ci = ci0 + k, co = co0 + threadIdx.x;
+        if (ci < Cin && co < Cout_pad) Elem<T>::st(wt + ((long)ci * RS + rs) * Cout_pad + co, tile[threadIdx.x][k]);
+    }
+}
+
 template <typename T>
 __global__ void weight_pad_k_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout, int K, int Kpad) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -130,6 +164,15 @@ extern "C" int mpn_weight_transpose(const float* w, void* wt, int Cout, int RS, 
     dim3 grid((Cin + 31) / 32, (Cout_pad + 31) / 32, RS), block(32, 8);
     if (dtype == MPN_F32) hipLaunchKernelGGL(weight_transpose_kernel<float>, grid, block, 0, (hipStream_t)stream, w, (float*)wt, Cout, RS, Cin, Cout_pad);
     else hipLaunchKernelGGL(weight_transpose_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, w, (bf16_t*)wt, Cout, RS, Cin, Cout_pad);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_weight_transpose_batched(const float* arena, void* dst, const int64_t* table, int nlayers, int64_t nblocks,
+                                            int dtype, void* stream) {
+    MPN_CHECK_ARG(arena && dst && table && nlayers > 0 && nblocks > 0 && nblocks < 0x7fffffffLL);
+    dim3 grid((unsigned)nblocks), block(32, 8);
+    if (dtype == MPN_F32) hipLaunchKernelGGL(weight_transpose_batched_kernel<float>, grid, block, 0, (hipStream_t)stream, arena, (float*)dst, (const long*)table, nlayers);
+    else hipLaunchKernelGGL(weight_transpose_batched_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, arena, (bf16_t*)dst, (const long*)table, nlayers);
     return mpn_launch_status();
 }
 

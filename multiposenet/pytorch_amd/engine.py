@@ -30,6 +30,7 @@ class Ctx(object):
         self.keep = []           # keeps Acts alive while their id() is used as a key
         self.out_grads = {}      # export slot -> torch grad tensor (filled by _NetFn.backward)
         self.wt = {}             # id(weight param) -> transposed operand
+        self.wt_buf = None       # one buffer holding every layer's transposed operand for this pass
         self.uses = {}           # id(param) -> number of pending gradient contributions
         self.bn_train_ran = False
         self.side_keep = []      # operands of side-stream launches, kept alive until the streams join
@@ -68,6 +69,7 @@ class Engine(object):
         self.m = model
         self._drop_calls = 0
         self._side = None
+        self._wt_plan_cache = None
         self.overlap_wgrad = os.environ.get("MPN_SIDE_STREAM", "1") != "0"
 
     def side_stream(self, device):
@@ -106,17 +108,58 @@ class Engine(object):
             return ar.data_seg(layer.weight)
         return ar.data_seg(layer.weight, ar.bf16)
 
+    def _wt_plan(self):
+        """Layout of every conv / linear layer's dgrad operand Wt[Cin][R][S][Cout_pad] inside one buffer, plus the device
+        table mpn_weight_transpose_batched walks (built once per arena)."""
+        ar = self.m._arena
+        plan = self._wt_plan_cache
+        if plan is not None and plan["arena"] is ar and plan["dtype"] == self.cdt:
+            return plan
+        kc = 32 if self.cdt == torch.bfloat16 else 16
+        rows, views, off, blk = [], {}, 0, 0
+        stem = self.m.fpn.conv1.weight
+        for mod in self.m.modules():
+            w = getattr(mod, "weight", None)
+            if not isinstance(mod, (torch.nn.Conv2d, torch.nn.Linear)) or w is None or id(w) not in ar.index or w is stem:
+                continue
+            if id(w) in views:
+                continue
+            O, I, R, S, _, _ = _geom(mod)
+            opad = round_up(O, kc)
+            gx, gy = (I + 31) // 32, (opad + 31) // 32
+            rows.append([ar.offsets[ar.index[id(w)]], off, O, R * S, I, opad, blk, gx])
+            views[id(w)] = (off, (I, R, S, opad))
+            off += round_up(I * R * S * opad, 64)
+            blk += gx * gy * R * S
+        plan = {"arena": ar, "dtype": self.cdt, "views": views, "total": off, "blocks": blk, "n": len(rows),
+                "table": torch.tensor(rows, dtype=torch.int64, device=ar.flat.device)}
+        self._wt_plan_cache = plan
+        return plan
+
     def w_t(self, ctx, layer):
-        """dgrad operand Wt[Cin][R][S][Cout_pad], refreshed once per forward."""
+        """dgrad operand Wt[Cin][R][S][Cout_pad]: all layers are transposed by ONE launch the first time a forward
+        pass asks for one (a buffer per pass, so a later optimizer step cannot change what this tape will read)."""
         key = id(layer.weight)
         wt = ctx.wt.get(key)
-        if wt is None:
+        if wt is not None:
+            return wt
+        plan = self._wt_plan()
+        if key not in plan["views"]:          # not an arena conv/linear weight: single transpose
             O, I, R, S, _, _ = _geom(layer)
             kc = 32 if self.cdt == torch.bfloat16 else 16
             opad = round_up(O, kc)
             wt = torch.empty((I, R, S, opad), dtype=self.cdt, device=layer.weight.device)
             ops.weight_transpose(self.m._arena.data_seg(layer.weight), wt, O, R * S, I, opad)
             ctx.wt[key] = wt
+            return wt
+        if ctx.wt_buf is None:
+            ctx.wt_buf = torch.empty(plan["total"], dtype=self.cdt, device=plan["table"].device)
+            call("mpn_weight_transpose_batched", ops.ptr(self.m._arena.flat), ops.ptr(ctx.wt_buf), ops.ptr(plan["table"]),
+                 plan["n"], plan["blocks"], ops.dtype_code(self.cdt), ops.stream_ptr())
+        off, shape = plan["views"][key]
+        n = shape[0] * shape[1] * shape[2] * shape[3]
+        wt = ctx.wt_buf[off: off + n].view(shape)
+        ctx.wt[key] = wt
         return wt
 
     def _note_use(self, ctx, p):
@@ -491,5 +534,6 @@ class Engine(object):
         ctx.keep = []
         ctx.side_keep = []
         ctx.wt.clear()
+        ctx.wt_buf = None
         if m._reducer is not None:
             m._reducer.finish()
