@@ -317,15 +317,15 @@ constexpr unsigned DMA_OOB = 0x80000000u;     // tensors are < 2 GB (launcher ch
 // Tile image in LDS: 32 pixel rows of ROWB = tile_channels * 2 bytes, back to back.  ds_read_b64_tr_b16 is serviced in
 // two 32-lane halves; one half touches 8 rows (k = {0..3} + 8*{0,1} + 4h) x 32 bytes, which must land on 8 distinct
 // 32-byte bank slots of the 256-byte bank row.  256-byte rows: every row starts on slot 0, so the 32-byte piece index
-// is XORed with (k&3)|((k>>3)&1)<<2.  128-byte rows: rows k and k+1 already differ by 4 slots, the remaining four
+// is XORed with (k&3)|((k>>3)&1)<<2 (512-byte rows likewise: the row stride is a multiple of the bank row).  128-byte rows: rows k and k+1 already differ by 4 slots, the remaining four
 // rows of equal parity are separated by XORing the piece index with ((k>>1)&1)|((k>>3)&1)<<1.  Swizzles are in
 // 16-byte chunk units (piece << 1) and are applied on the DMA source side.
 template <int ROWB> __device__ __forceinline__ int dma_swz(int k) {
-    return ROWB == 256 ? 2 * ((k & 3) | (((k >> 3) & 1) << 2)) : 2 * (((k >> 1) & 1) | (((k >> 3) & 1) << 1));
+    return ROWB >= 256 ? 2 * ((k & 3) | (((k >> 3) & 1) << 2)) : 2 * (((k >> 1) & 1) | (((k >> 3) & 1) << 1));
 }
 
 template <int TM, int TN>
-__global__ void __launch_bounds__(256, 3) conv_wgrad_dma_kernel(const MpnWgradParams p, long chunk_pixels) {
+__global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_kernel(const MpnWgradParams p, long chunk_pixels) {
     constexpr int KP = 32, NST = 3;
     constexpr int ROWA = TM * 2, ROWB = TN * 2;              // bytes per pixel row of each tile
     constexpr int A_BYTES = KP * ROWA, B_BYTES = KP * ROWB;
@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_dma_kernel(const MpnWgradPa
     constexpr int QA = A_BYTES / 4096, QB = B_BYTES / 4096;  // DMA instructions (1 KiB each) per wave per k-step
     constexpr int RPA = 1024 / ROWA, RPB = 1024 / ROWB;      // tile rows covered by one instruction
     constexpr int MM = TM / 32, MN = TN / 32;                // 16x16 fragments per wave (2 x 2 waves)
-    static_assert((TM == 128 || TM == 64) && (TN == 128 || TN == 64), "tiles are 64 or 128 channels wide");
+    static_assert((TM == 256 || TM == 128 || TM == 64) && (TN == 128 || TN == 64), "tile widths");
     __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -537,9 +537,24 @@ inline bool wgrad_uses_dma(const MpnWgradParams& p) {
     return p.dtype == MPN_BF16 && use_dma && small && p.Cin % 8 == 0;
 }
 
+constexpr long kWgradTarget = 512;       // workgroups per launch (~2 per CU): long slices, little partial-sum traffic
+
 inline void wgrad_tiles(const MpnWgradParams& p, int& tm, int& tn) {
     tm = pick_tile(p.Cin); tn = pick_tile(p.Cout);
-    if (wgrad_uses_dma(p)) { if (tm < 64) tm = 64; if (tn < 64) tn = 64; }
+    if (!wgrad_uses_dma(p)) return;
+    if (tm < 64) tm = 64;
+    if (tn < 64) tn = 64;
+    // A 256 x 128 tile moves a third less data per FLOP through the DMA/LDS path (it pays in conv_igemm), but here it
+    // measured SLOWER (3x3 256->256 @60x60: 243 vs 208 us, 512->256 @120x120: 1595 vs 1431 us): with two workgroups
+    // per CU the transpose reads are no longer hidden and the slice count (partial-sum traffic) doubles.  Kept behind
+    // MPN_WGRAD_TM256_MIN_STEPS (minimum k-steps per workgroup) for experiments, off by default.
+    static const long min_steps = getenv("MPN_WGRAD_TM256_MIN_STEPS") ? atol(getenv("MPN_WGRAD_TM256_MIN_STEPS")) : (1L << 40);
+    if (p.Cin >= 256 && tn == 128) {
+        const long tiles = (long)((p.Cin + 255) / 256) * ((p.Cout + 127) / 128) * p.R * p.S;
+        const long chunks = (kWgradTarget + tiles - 1) / tiles;
+        const long P = (long)p.B * p.Ho * p.Wo;
+        if (P / 32 / chunks >= min_steps) tm = 256;
+    }
 }
 
 template <typename T>
@@ -556,7 +571,8 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st, bool reduce = true) {
     int rc;
     const dim3 g((unsigned)grid), blk(256);
     if (sizeof(T) == 2 && wgrad_uses_dma(p)) {
-        if (tm == 128 && tn == 128) hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 128>), g, blk, 0, st, p, chunk_pixels);
+        if (tm == 256) hipLaunchKernelGGL((conv_wgrad_dma_kernel<256, 128>), g, blk, 0, st, p, chunk_pixels);
+        else if (tm == 128 && tn == 128) hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 128>), g, blk, 0, st, p, chunk_pixels);
         else if (tm == 128) hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 64>), g, blk, 0, st, p, chunk_pixels);
         else if (tn == 128) hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 128>), g, blk, 0, st, p, chunk_pixels);
         else hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 64>), g, blk, 0, st, p, chunk_pixels);
@@ -579,7 +595,7 @@ extern "C" int mpn_conv_wgrad_chunks(const MpnWgradParams* p) {
     wgrad_tiles(*p, tm, tn);
     const long tiles = (long)((p->Cin + tm - 1) / tm) * ((p->Cout + tn - 1) / tn) * p->R * p->S;
     const long P = (long)p->B * p->Ho * p->Wo;
-    static const long target = getenv("MPN_WGRAD_TARGET") ? atol(getenv("MPN_WGRAD_TARGET")) : 512;
+    static const long target = getenv("MPN_WGRAD_TARGET") ? atol(getenv("MPN_WGRAD_TARGET")) : kWgradTarget;
     static const long minpix = getenv("MPN_WGRAD_MINPIX") ? atol(getenv("MPN_WGRAD_MINPIX")) : 512;
     long want = (target + tiles - 1) / tiles;          // ~2 workgroups per CU: with the DMA ring long slices run near peak and partial-sum traffic dominates
     const long maxc = (P + minpix - 1) / minpix;       // keep >= 512 pixels per slice
