@@ -174,6 +174,62 @@ def test_wgrad_large_split():
         assert torch.equal(dw, dw2), "wgrad must be run-to-run deterministic"
 
 
+def test_wgrad_partials_entry_point_matches_fused_call():
+    """mpn_conv_wgrad_partials + mpn_reduce_partials (the profiler-bracketed path ops.conv_wgrad takes when kernel
+    events are on) must produce exactly what the single mpn_conv_wgrad call does; every LDS-DMA tile variant."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    for (Cin, Cout) in ((128, 256), (64, 64), (256, 36), (32, 128)):
+        B, H, W = 4, 40, 40
+        x = rnd(dtype, rng_normal(34, B, Cin, H, W))
+        dy = rnd(dtype, rng_normal(35, B, Cout, H, W))
+        dw = torch.zeros((Cout, 1, 1, Cin), dtype=torch.float32, device="cuda")
+        ops.conv_wgrad(to_act(x, dtype), to_act(dy, dtype), dw, Cout, 1, 1, 1, 0)
+        dw2 = torch.zeros_like(dw)
+        ops.KERNEL_EVENTS.enable()
+        try:
+            ops.conv_wgrad(to_act(x, dtype), to_act(dy, dtype), dw2, Cout, 1, 1, 1, 0)
+            names = [r[0] for r in ops.KERNEL_EVENTS.rec]
+        finally:
+            ops.KERNEL_EVENTS.disable()
+        assert torch.equal(dw, dw2)
+        assert names and names[0].startswith("conv_wgrad_dma_kernel<"), names
+        ref = torch.einsum("bohw,bihw->oi", dy.float().cpu(), x.float().cpu())
+        check_close("wgrad dma tile %dx%d" % (Cin, Cout), dw.cpu().view(Cout, Cin), ref, dtype)
+
+
+def test_weight_transpose_batched_matches_per_layer():
+    """One launch over a table of layers == mpn_weight_transpose per layer (bf16 and f32 operands)."""
+    ops = _ops()
+    from multiposenet.pytorch_amd import _lib
+    geoms = [(64, 9, 64), (19, 1, 256), (256, 1, 1024), (36, 9, 256), (128, 49, 3 * 8)]       # (Cout, RS, Cin)
+    for dtype in DTYPES:
+        kc = 32 if dtype == torch.bfloat16 else 16
+        arena, rows, off_src, off_dst, blk = [], [], 0, 0, 0
+        for O, RS, I in geoms:
+            w = rng_normal(50 + O, O * RS * I)
+            arena.append(w)
+            opad = (O + kc - 1) // kc * kc
+            gx, gy = (I + 31) // 32, (opad + 31) // 32
+            rows.append([off_src, off_dst, O, RS, I, opad, blk, gx])
+            off_src += O * RS * I
+            off_dst += (I * RS * opad + 63) // 64 * 64
+            blk += gx * gy * RS
+        flat = torch.cat(arena).cuda()
+        table = torch.tensor(rows, dtype=torch.int64, device="cuda")
+        dst = torch.full((off_dst,), 7.0, dtype=dtype, device="cuda")
+        _lib.call("mpn_weight_transpose_batched", ops.ptr(flat), ops.ptr(dst), ops.ptr(table), len(rows), blk,
+                  ops.dtype_code(dtype), ops.stream_ptr())
+        for (O, RS, I), row in zip(geoms, rows):
+            opad = row[5]
+            one = torch.empty((I, RS, opad), dtype=dtype, device="cuda")
+            ops.weight_transpose(flat[row[0]: row[0] + O * RS * I], one, O, RS, I, opad)
+            got = dst[row[1]: row[1] + I * RS * opad].view(I, RS, opad)
+            assert torch.equal(got, one), "batched transpose differs for layer %s" % ((O, RS, I),)
+            ref = flat[row[0]: row[0] + O * RS * I].view(O, RS, I).permute(2, 1, 0).to(dtype)
+            assert torch.equal(got[:, :, :O], ref) and bool((got[:, :, O:] == 0).all())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("C", [64, 256, 2048])
 def test_batchnorm_train_and_eval(dtype, C):
