@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--event-every", type=int, default=4, help="bracket conv launches with HIP events on every n-th timed step")
+    ap.add_argument("--event-every", type=int, default=8, help="bracket conv launches with HIP events on every n-th timed step")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and the gradient reducer even with one rank")
