@@ -243,6 +243,15 @@ int mpn_fill_f32(float* dst, float v, int64_t n, void* stream);
 /* library self-description */
 const char* mpn_version(void);
 
+/* ---------------------------------------------------------------------------------------------
+ * Ground-truth heat-maps (datasets/coco_data/heatmap.py:20-41 + COCO_data_pipeline.py:218-236,283):
+ * out[b][k][y][x] (f32, 18 keypoint channels) = min(1, sum over people j < num_people[b] with
+ * visibility <= 1 of exp(-e) where e = d2/2/sigma/sigma <= 4.6052), float64 arithmetic in annotation
+ * order.  joints: double [B][maxP][18][3] = (x, y, visibility) in crop pixels.
+ * -------------------------------------------------------------------------------------------*/
+int mpn_gt_heatmaps(const double* joints, const int32_t* num_people, int B, int maxP, float* out, int gh, int gw,
+                    double stride, double sigma, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

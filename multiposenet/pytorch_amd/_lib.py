@@ -56,6 +56,7 @@ _PW = ctypes.POINTER(WgradParams)
 # name -> (restype, argtypes); mirrors include/mpn.h one to one (tests/test_capi.py checks this table
 # against the header and against the exported dynamic symbols).
 SIGNATURES = {
+    "mpn_gt_heatmaps": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, ctypes.c_double, ctypes.c_double, _vp]),
     "mpn_conv_stats_tiles": (_i, [_PC]),
     "mpn_conv_tile_rows": (_i, [_PC]),
     "mpn_conv_forward": (_i, [_PC, _vp]),

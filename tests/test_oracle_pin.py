@@ -178,3 +178,17 @@ def test_three_adam_steps_restatement_vs_reference():
         loss.backward()
         opt.step()
         assert abs(loss.item() - g["losses"][step, 0]) <= 2e-4 * g["losses"][step, 0], (step, loss.item())
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_gt_heatmap_restatement_vs_reference(case):
+    """oracle/heatmap_oracle.py vs maps rendered by the reference's own putGaussianMaps (heatmap.py:20-41): bit-exact,
+    including the 1.0 clamp, keypoints outside the crop, skipped (visibility 2) keypoints and an image without people."""
+    from oracle import heatmap_oracle as ho
+    g = gold("g9_gt_heatmaps.npz")
+    crop, stride, sigma = (float(v) for v in g["cfg_" + case])
+    out = ho.gt_heatmaps(g["joints_" + case], g["num_" + case], crop, crop, stride, sigma)
+    ref = g["out_" + case]
+    assert out.dtype == np.float32 and out.shape == ref.shape
+    assert np.array_equal(out, ref)
+    assert float(ref.max()) == 1.0 and int(g["num_" + case][1]) == 0 and not ref[1].any()
