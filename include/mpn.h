@@ -252,6 +252,18 @@ const char* mpn_version(void);
 int mpn_gt_heatmaps(const double* joints, const int32_t* num_people, int B, int maxP, float* out, int gh, int gw,
                     double stride, double sigma, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Heat-map peak extraction (network/joint_utils.py:19-31 find_peaks, :61-138 NMS).  heat: f32, element
+ * (b, j, y, x) at heat[b*sB + j*sJ + y*sY + x*sX].  A cell is a peak if it is > thre1 and no 4-neighbour
+ * is larger.  peaks[b][j][slot][4] = (x, y, score, id) as doubles, slots in row-major cell order, ids
+ * counted over joints 0..J-1 in that order; with refine != 0 the position/score come from the bicubically
+ * (cv2 INTER_CUBIC) `upsamp`-times up-sampled 5x5 patch around the cell, else from the cell itself
+ * ((c + 0.5)*upsamp - 0.5, rounded half to even).  counts[b][j] = number of peaks found (only the first
+ * `cap` are stored).
+ * -------------------------------------------------------------------------------------------*/
+int mpn_heatmap_peaks(const float* heat, int64_t sB, int64_t sJ, int64_t sY, int64_t sX, int B, int J, int H, int W,
+                      float thre1, double upsamp, int refine, double* peaks, int32_t* counts, int cap, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

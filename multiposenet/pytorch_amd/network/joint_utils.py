@@ -1,0 +1,68 @@
+"""Heat-map peak extraction on the GPU — the device half of the reference's ``network/joint_utils.py``.
+
+Mirrors ``find_peaks`` (joint_utils.py:19-31), ``NMS`` (:61-138) and ``get_joint_list`` (:141-152) with the same
+signatures and return structures, but the heat-maps stay on the device: the 3x3-cross maximum filter, the threshold, the
+row-major compaction, the 5x5-patch bicubic refinement and the running peak ids are one kernel launch per batch
+(``mpn_heatmap_peaks``) instead of scipy/cv2 calls per joint and per peak on the host.  Only the (few dozen) peaks cross
+PCIe.  The drawing helpers of the reference file (cv2) are out of scope.
+"""
+import numpy as np
+import torch
+
+from .._lib import MpnError, call
+from .. import ops
+
+NUM_JOINTS = 18                      # joint_utils.py:16
+DEFAULT_CAP = 256                    # peaks kept per joint type (the reference has no limit; an overflow raises)
+
+
+def _peaks_device(heat_bjhw, thre1, upsamp, refine, cap=DEFAULT_CAP):
+    """heat_bjhw: CUDA float32 tensor viewed as [B, J, H, W] (any strides).  Returns (peaks [B,J,cap,4] f64, counts [B,J])."""
+    if not heat_bjhw.is_cuda:
+        raise MpnError("heat-map peak extraction runs on the MI355X only; there is no CPU path")
+    if heat_bjhw.dtype != torch.float32 or heat_bjhw.dim() != 4:
+        raise MpnError("heat-maps must be a float32 [B, J, H, W] view")
+    B, J, H, W = heat_bjhw.shape
+    sB, sJ, sY, sX = heat_bjhw.stride()
+    peaks = torch.empty((B, J, cap, 4), dtype=torch.float64, device=heat_bjhw.device)
+    counts = torch.empty((B, J), dtype=torch.int32, device=heat_bjhw.device)
+    call("mpn_heatmap_peaks", ops.ptr(heat_bjhw), sB, sJ, sY, sX, B, J, H, W, float(thre1), float(upsamp), 1 if refine else 0,
+         ops.ptr(peaks), ops.ptr(counts), cap, ops.stream_ptr())
+    return peaks, counts
+
+
+def _split(peaks, counts, cap):
+    peaks, counts = peaks.cpu().numpy(), counts.cpu().numpy()          # one D2H of the compact result
+    if int(counts.max(initial=0)) > cap:
+        raise MpnError("more than %d peaks of one joint type in an image; raise `cap`" % cap)
+    return [[peaks[b, j, :counts[b, j]].copy() for j in range(peaks.shape[1])] for b in range(peaks.shape[0])]
+
+
+def find_peaks(param, img):
+    """joint_utils.py:19-31.  img: CUDA float32 [H, W].  Returns an int array [[x, y], ...] in row-major order."""
+    pk, cnt = _peaks_device(img[None, None], param['thre1'], 1.0, False)
+    out = _split(pk, cnt, DEFAULT_CAP)[0][0]
+    return out[:, :2].astype(np.int64)
+
+
+def NMS(param, heatmaps, upsampFactor=1., bool_refine_center=True, bool_gaussian_filt=False, cap=DEFAULT_CAP):
+    """joint_utils.py:61-138.  heatmaps: CUDA float32 tensor [H, W, J] (any strides, e.g. ``pred[0].permute(1, 2, 0)``).
+    Returns the reference's list of J arrays [n, 4] = (x, y, score, id)."""
+    if bool_gaussian_filt:
+        raise MpnError("bool_gaussian_filt=True (off by default in the reference, joint_utils.py:61) is not built")
+    pk, cnt = _peaks_device(heatmaps.permute(2, 0, 1)[None], param['thre1'], upsampFactor, bool_refine_center, cap)
+    return _split(pk, cnt, cap)[0]
+
+
+def NMS_batch(param, pred, upsampFactor=1., bool_refine_center=True, cap=DEFAULT_CAP):
+    """All images of a ``[B, J, H, W]`` heat-map tensor in one launch; a list (per image) of NMS() results."""
+    pk, cnt = _peaks_device(pred, param['thre1'], upsampFactor, bool_refine_center, cap)
+    return _split(pk, cnt, cap)
+
+
+def get_joint_list(img_orig, param, heatmaps, scale):
+    """joint_utils.py:141-152: rows (x*scale, y*scale, score, id, joint_type)."""
+    per_type = NMS(param, heatmaps, img_orig.shape[0] / float(heatmaps.shape[0]))
+    for peaks in per_type:
+        peaks[:, :2] = peaks[:, :2] * scale
+    return np.array([tuple(peak) + (joint_type,) for joint_type, joint_peaks in enumerate(per_type) for peak in joint_peaks])

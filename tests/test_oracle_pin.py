@@ -192,3 +192,20 @@ def test_gt_heatmap_restatement_vs_reference(case):
     assert out.dtype == np.float32 and out.shape == ref.shape
     assert np.array_equal(out, ref)
     assert float(ref.max()) == 1.0 and int(g["num_" + case][1]) == 0 and not ref[1].any()
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_peak_extraction_restatement_vs_reference(case):
+    """oracle/joint_oracle.py vs the reference's own find_peaks / NMS(bool_refine_center=False) (joint_utils.py:19-31,
+    61-138): exact.  The cv2-bicubic refinement branch has a reference golden only if g10 was made on a box with cv2."""
+    from oracle import joint_oracle as jo
+    g = gold("g10_peaks.npz")
+    heat, up = g["heat_" + case], float(g["up_" + case])
+    fp = [jo.find_peaks(0.1, heat[:, :, j]) for j in range(18)]
+    assert np.array_equal(np.array([len(p) for p in fp]), g["fp_counts_" + case])
+    assert np.array_equal(np.concatenate([p.reshape(-1, 2) for p in fp]), g["fp_xy_" + case])
+    plain = np.concatenate([p.reshape(-1, 4) for p in jo.nms_peaks(0.1, heat, up, refine=False)])
+    assert np.array_equal(plain, g["nms_plain_" + case])
+    if int(g["refined"]) == 1:
+        refd = np.concatenate([p.reshape(-1, 4) for p in jo.nms_peaks(0.1, heat, up, refine=True)])
+        assert np.array_equal(refd, g["nms_refined_" + case])
