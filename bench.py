@@ -174,6 +174,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly one JSON line: RCCL prints a version banner to fd 1 when its first communicator comes up,
+    # so fd 1 points at stderr until the result line is written
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     use_dist = world > 1 or args.force_dist
     if use_dist:
@@ -293,7 +298,10 @@ def main():
             out["kernel_classes_ms_per_step"] = {k: round(v["ms"] / ev_steps, 3) for k, v in sorted(ke.items(), key=lambda kv: -kv[1]["ms"])}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.destroy_process_group()
 
