@@ -3,6 +3,8 @@
 by fused HIP kernels (csrc/losses.hip) instead of per-image python loops and ~60 tiny ATen kernels.
 """
 import ctypes
+import numbers
+import os
 from collections import OrderedDict
 
 import torch
@@ -66,6 +68,97 @@ class _HeatmapMSE(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+class _LazyVec(object):
+    """Device -> host copy of a small log vector that does not stall the launch stream: the copy is enqueued behind the
+    kernels that produce the values (pinned destination, non-blocking) and only waited for when somebody reads one."""
+
+    def __init__(self, t):
+        self._host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        self._host.copy_(t.detach(), non_blocking=True)
+        self._ev = torch.cuda.Event()
+        self._ev.record()
+        self._vals = None
+
+    def get(self):
+        if self._vals is None:
+            self._ev.synchronize()
+            self._vals = self._host.tolist()
+            self._host = None
+        return self._vals
+
+
+class LazyFloat(numbers.Real):
+    """A log value that becomes a Python float the moment it is used (printed, formatted, added to a meter ...).
+
+    The reference's build_*_loss return floats obtained with ``.item()`` (posenet.py:383-401, :417-423), i.e. a host
+    sync between forward and backward in every step.  The trainer only looks at them after ``optimizer.step()``
+    (trainer.py:251-262), so the values are fetched asynchronously and materialised on first use; ``MPN_EAGER_LOG=1``
+    restores plain floats."""
+    __slots__ = ("_src", "_i")
+
+    def __init__(self, src, i):
+        self._src, self._i = src, i
+
+    def __float__(self):
+        return float(self._src.get()[self._i])
+
+    item = __float__
+
+    def __repr__(self):
+        return repr(float(self))
+
+    __str__ = __repr__
+
+    def __format__(self, spec):
+        return format(float(self), spec)
+
+    def __hash__(self):
+        return hash(float(self))
+
+    def __bool__(self):
+        return bool(float(self))
+
+    def __int__(self):
+        return int(float(self))
+
+    def __array__(self, dtype=None, copy=None):
+        import numpy as np
+        return np.asarray(float(self), dtype=dtype)
+
+    def __abs__(self): return abs(float(self))
+    def __neg__(self): return -float(self)
+    def __pos__(self): return float(self)
+    def __trunc__(self): return float(self).__trunc__()
+    def __floor__(self): return float(self).__floor__()
+    def __ceil__(self): return float(self).__ceil__()
+    def __round__(self, n=None): return round(float(self), n)
+    def __add__(self, o): return float(self) + o
+    def __radd__(self, o): return o + float(self)
+    def __sub__(self, o): return float(self) - o
+    def __rsub__(self, o): return o - float(self)
+    def __mul__(self, o): return float(self) * o
+    def __rmul__(self, o): return o * float(self)
+    def __truediv__(self, o): return float(self) / o
+    def __rtruediv__(self, o): return o / float(self)
+    def __floordiv__(self, o): return float(self) // o
+    def __rfloordiv__(self, o): return o // float(self)
+    def __mod__(self, o): return float(self) % o
+    def __rmod__(self, o): return o % float(self)
+    def __pow__(self, o): return float(self) ** o
+    def __rpow__(self, o): return o ** float(self)
+    def __eq__(self, o): return float(self) == o
+    def __lt__(self, o): return float(self) < o
+    def __le__(self, o): return float(self) <= o
+
+
+def _log_values(t):
+    """Python-visible values of a small device vector: floats (eager mode) or LazyFloat proxies."""
+    if os.environ.get("MPN_EAGER_LOG", "0") == "1" or not t.is_cuda:
+        return t.detach().cpu().tolist()
+    src = _LazyVec(t)
+    return [LazyFloat(src, i) for i in range(t.numel())]
+
+
 def build_names():
     names = []
     for j in range(2, 6):
@@ -82,7 +175,7 @@ def build_keypoint_loss(saved_for_loss, heat_temp, heat_weight):
     heat = ops.nchw_to_nhwc_f32(heat_temp.detach().float())
     wgt = ops.nchw_to_nhwc_f32(heat_weight.detach().float())
     total, out = _HeatmapMSE.apply(heat, wgt, *saved_for_loss[:5])
-    vals = out.cpu().tolist()       # one D2H copy instead of the reference's seven .item() syncs
+    vals = _log_values(out)         # one asynchronous D2H copy instead of the reference's seven .item() syncs
     log = OrderedDict()
     for j in range(5):
         log[names[j * 2]] = vals[j]
@@ -142,6 +235,6 @@ def build_detection_loss(saved_for_loss, anno):
     closs = closs.mean()
     rloss = rloss.mean()
     total = closs + rloss
-    vals = torch.stack([total.detach(), closs.detach(), rloss.detach()]).cpu().tolist()
+    vals = _log_values(torch.stack([total.detach(), closs.detach(), rloss.detach()]))
     log['total_loss'], log['classification_loss'], log['regression_loss'] = vals
     return total, log

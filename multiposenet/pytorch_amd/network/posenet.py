@@ -32,7 +32,7 @@ from ..lib.nms.pth_nms import pth_nms
 from . import losses
 from .anchors import Anchors
 from .fpn import FPN50, FPN101
-from .losses import build_detection_loss, build_keypoint_loss, build_names  # noqa: F401  (reference exports)
+from .losses import build_detection_loss, build_keypoint_loss, build_names, _log_values  # noqa: F401  (reference exports)
 from .utils import BBoxTransform, ClipBoxes, decode_and_clip
 
 
@@ -469,5 +469,5 @@ def build_prn_loss(saved_for_loss, label):
     """posenet.py:427-445: BCELoss(size_average=True)(out, label)."""
     saved_for_log = OrderedDict()
     total_loss = _BCEMean.apply(saved_for_loss[0], label)
-    saved_for_log['PRN loss'] = total_loss.item()
+    saved_for_log['PRN loss'] = _log_values(total_loss.detach().reshape(1))[0]
     return total_loss, saved_for_log
