@@ -83,8 +83,10 @@ class Engine(object):
             self._side = torch.cuda.Stream(device=device)
         return self._side
 
-    def _on_side(self, ctx, device, keep, fn):
-        """Run fn() on the side stream, ordered after everything enqueued so far on the current stream."""
+    def _on_side(self, ctx, device, keep, fn, torch_ops=False):
+        """Run fn() on the side stream, ordered after everything enqueued so far on the current stream.  Our own
+        launches take the stream explicitly (ops.push_stream); only closures that also run torch ops (torch_ops=True)
+        pay for switching torch's current stream."""
         side = self.side_stream(device)
         if side is None:
             fn()
@@ -92,9 +94,16 @@ class Engine(object):
         ev = torch.cuda.Event()
         ev.record()
         ctx.side_keep.append(keep)
-        with torch.cuda.stream(side):
-            side.wait_event(ev)
+        side.wait_event(ev)
+        if torch_ops:
+            with torch.cuda.stream(side):
+                fn()
+            return
+        ops.push_stream(side)
+        try:
             fn()
+        finally:
+            ops.pop_stream()
 
     # ------------------------------------------------------------------ weights
     @property
@@ -389,7 +398,7 @@ class Engine(object):
                         dwp = torch.zeros((64, 7, 32), dtype=torch.float32, device=img.device)
                         ops.conv_wgrad(xa, dy, dwp, 64, 7, 1, 2, 0, cin=32, x_geom=geom)
                         call("mpn_stem_unpack_wgrad", ops.ptr(dwp), ops.ptr(self.m._arena.grad_seg(w)), 64, ops.stream_ptr())
-                    self._on_side(ctx, dy.t.device, (xa, dy), stem_wgrad)
+                    self._on_side(ctx, dy.t.device, (xa, dy), stem_wgrad, torch_ops=True)
                 self._grad_done(ctx, w)
             ctx.tape.append(bwd)
         z = self.bn(ctx, y, st, f.bn1, True)

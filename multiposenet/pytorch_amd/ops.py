@@ -23,8 +23,33 @@ def dtype_code(dt):
     raise _lib.MpnError("unsupported dtype %s" % dt)
 
 
+# Launch stream.  Kernels go to torch's current stream unless the engine has pushed an explicit one (the weight-gradient
+# side stream): switching torch's current stream with `torch.cuda.stream(...)` costs ~20 us of Python per use, and
+# torch.cuda.current_stream() ~8 us per launch; the raw-handle query below is two C calls.
+_STREAM_OVERRIDE = []          # stack of (raw handle, torch.cuda.Stream)
+
+
+def push_stream(stream):
+    _STREAM_OVERRIDE.append((stream.cuda_stream, stream))
+
+
+def pop_stream():
+    _STREAM_OVERRIDE.pop()
+
+
+def stream_handle():
+    if _STREAM_OVERRIDE:
+        return _STREAM_OVERRIDE[-1][0]
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+def stream_obj():
+    """torch.cuda.Stream to record events on (None = torch's current stream)."""
+    return _STREAM_OVERRIDE[-1][1] if _STREAM_OVERRIDE else None
+
+
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(stream_handle())
 
 
 def ptr(t):
@@ -82,12 +107,12 @@ class _KernelEvents(object):
 
     def begin(self):
         e = torch.cuda.Event(enable_timing=True)
-        e.record()
+        e.record(stream_obj())
         return e
 
     def end(self, name, flops, e0):
         e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
+        e1.record(stream_obj())
         self.rec.append((name, flops, e0, e1))
 
     def summary(self):
@@ -108,10 +133,15 @@ _ws = {}
 def workspace(nbytes, device, slot=0):
     """Persistent scratch (grown geometrically); one buffer per (device, slot)."""
     # one buffer per stream as well: launches on different streams must not share (or re-grow) a scratch area
-    key = (str(device), slot, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    key = (device, slot, stream_handle() if device.type == "cuda" else 0)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
+        so = stream_obj()
+        if buf is not None and so is not None:
+            buf.record_stream(so)        # the outgoing buffer may still be read by launches queued on the pushed stream
         buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        if so is not None:
+            buf.record_stream(so)
         _ws[key] = buf
     return buf
 
