@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--eager-log", action="store_true", help="plain-float loss logs (one host sync per step, the reference's behaviour)")
     ap.add_argument("--event-every", type=int, default=8, help="bracket conv launches with HIP events on every n-th timed step")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-baseline-worker", action="store_true")
@@ -197,6 +198,8 @@ def main():
     from multiposenet.pytorch_amd import ddp, ops
     from multiposenet.pytorch_amd.network.posenet import poseNet
     from multiposenet.pytorch_amd.optim import FusedAdam
+    from multiposenet.pytorch_amd.network import losses as mpn_losses
+    mpn_losses.set_lazy_log(not args.eager_log)     # the log dict is not read inside the timed loop (trainer.py reads it after step())
 
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = poseNet(args.layers, compute_dtype=cdt).to(dev)
@@ -209,12 +212,15 @@ def main():
     opt = FusedAdam(model, lr=1e-4, weight_decay=0.0)
     img, heat, wgt, anno = synth(args.batch, args.size, dev, seed=100 + rank)
 
+    last_log = {}
+
     def step():
         pred, (ks, ds) = model([img, "train_both"])
         loss, log = poseNet.build_loss((ks, ds), "train_both", heat, wgt, anno)
         opt.zero_grad()
         loss.backward()
         opt.step()
+        last_log["log"] = log
         return loss
 
     for _ in range(args.warmup):
@@ -271,8 +277,11 @@ def main():
             "config": {"workload": "R%d full posenet (keypoint+detection) train step: fwd + MSE/focal losses + bwd + Adam, "
                                    "%dx%d, %d images/GPU, %s MFMA / fp32 accumulate / fp32 master weights"
                                    % (args.layers, args.size, args.size, args.batch, args.dtype),
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "loss_log": "eager floats (host sync per step)" if args.eager_log else "asynchronous (set_lazy_log)"},
         }
+        out["last_step_log"] = {k: round(float(v), 6) for k, v in last_log["log"].items()      # values exist, they were just
+                                if k in ("heatmap_loss", "total_loss", "classification_loss", "regression_loss")}   # not waited for
         out["host_enqueue_ms_per_step"] = round(t_enq / args.steps * 1000.0, 3)
         gf = GFLOP_PER_IMG_TRAIN.get(("r%d" % args.layers, args.size))
         if gf is not None:

@@ -370,3 +370,38 @@ def test_training_step_is_deterministic_and_stream_overlap_changes_nothing():
     finally:
         m._engine.overlap_wgrad = True
     report("train step R101 256x256 B=8: gradients bit-identical across 4 overlapped runs and the serial schedule")
+
+
+def test_loss_log_is_plain_floats_by_default_and_lazy_on_request():
+    """build_loss returns plain floats like the reference (posenet.py:383-401,417-423) unless set_lazy_log(True); the
+    lazy proxies are numbers.Real, carry the same values, and behave like floats in the arithmetic/formatting the
+    reference trainer applies (trainer.py:324-343)."""
+    import numbers
+    from oracle import weightgen
+    from multiposenet.pytorch_amd.network import losses
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    m = get_model(50, torch.float32)
+    m.eval()
+    b, s = 2, 64
+    img = t(weightgen.gen_images(4, b, s, s)).cuda()
+    heat, wgt = (t(a).cuda() for a in weightgen.gen_keypoint_gt(4, b, s // 4, s // 4))
+    anno = t(weightgen.gen_boxes_gt(4, b, s)).cuda()
+
+    def run():
+        with torch.no_grad():
+            _, (ks, ds) = m([img, "train_both"])
+            return poseNet.build_loss((ks, ds), "train_both", heat, wgt, anno)[1]
+    assert not losses.LAZY_LOG
+    eager = run()
+    assert all(type(v) is float for v in eager.values())
+    losses.set_lazy_log(True)
+    try:
+        lazy = run()
+    finally:
+        losses.set_lazy_log(False)
+    assert list(lazy.keys()) == list(eager.keys())
+    for k in eager:
+        v = lazy[k]
+        assert isinstance(v, numbers.Real) and not isinstance(v, float)
+        assert float(v) == eager[k] and v == eager[k] and v * 2 == eager[k] * 2 and 1 + v == 1 + eager[k]
+        assert "{:.10f}".format(v) == "{:.10f}".format(eager[k]) and repr(v) == repr(eager[k])
