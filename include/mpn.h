@@ -121,16 +121,18 @@ int mpn_bn_finalize_eval(int C, const float* gamma, const float* beta, const flo
 /* z = act(y*scale + shift [+ res]);  all [P][Cs] dense pixel-major with pixel stride Cs */
 int mpn_bn_act_forward(const void* y, const void* res, void* z, const float* scale, const float* shift,
                        int64_t P, int C, int Cs, int relu, int dtype, void* stream);
-/* backward, stage 1: g = dz * (z > 0 if relu); partial sums of g and g*xhat per channel */
+/* backward, stage 1: g = dz * (z > 0 if relu); partial sums of g and g*xhat per channel.
+ * With relu and z == NULL the mask is recomputed as (y*mask_scale + mask_shift) > 0 — the forward's own expression
+ * (valid when the forward had no residual input), which saves reading z. */
 int mpn_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
-                      float* partial, int chunks, int64_t P, int C, int Cs, int relu, int dtype, void* stream);
+                      const float* mask_scale, const float* mask_shift, float* partial, int chunks, int64_t P, int C, int Cs, int relu, int dtype, void* stream);
 /* backward, stage 2: reduce partials; dgamma += , dbeta += (if non-null); coef [3][C] = k1,k2,k3 with
  * dy = k1*g + k2*y + k3  (train: full batch-stat backward; train=0: k1 = gamma*invstd, k2 = k3 = 0) */
 int mpn_bn_bwd_finalize(const float* partial, int chunks, int C, int64_t count, const float* gamma, const float* mean,
                         const float* invstd, int train, float* dgamma, float* dbeta, float* coef, void* stream);
 /* backward, stage 3: dy = k1*g + k2*y + k3 (k2/k3 may be NULL = 0); dres (optional) receives / accumulates g */
 int mpn_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* k1, const float* k2, const float* k3,
-                     void* dy, void* dres, int dres_accumulate, int64_t P, int C, int Cs, int relu, int dtype, void* stream);
+                     const float* mask_scale, const float* mask_shift, void* dy, void* dres, int dres_accumulate, int64_t P, int C, int Cs, int relu, int dtype, void* stream);
 int mpn_bn_bwd_chunks(int64_t P, int Cs, int dtype);
 
 /* ---------------------------------------------------------------------------------------------

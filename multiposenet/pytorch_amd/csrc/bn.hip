@@ -128,25 +128,29 @@ __global__ void __launch_bounds__(256) bn_act_kernel(const T* __restrict__ y, co
 template <typename T>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ z, const T* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ mscale, const float* __restrict__ mshift,
                                                             float* __restrict__ partial, long P, int C, int Cs, int relu, int chunk_pix) {
     constexpr int V = Vec16<T>::N;
     __shared__ float sh[256][2 * V + 1];
     const Geo<T> q(Cs);
     const long p_begin = (long)blockIdx.x * chunk_pix;
     long p_end = p_begin + chunk_pix; if (p_end > P) p_end = P;
-    float s1[V], s2[V], mu[V], is[V];
+    float s1[V], s2[V], mu[V], is[V], sc[V], sf[V];
     load_coef<V>(mean, q.c0, C, mu, 0.f);
     load_coef<V>(invstd, q.c0, C, is, 0.f);
+    const bool remask = relu && z == nullptr;       // ReLU mask recomputed from y with bn_act's own expression (no z read)
+    if (remask) { load_coef<V>(mscale, q.c0, C, sc, 0.f); load_coef<V>(mshift, q.c0, C, sf, 0.f); }
 #pragma unroll
     for (int k = 0; k < V; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
     for (long p = p_begin + q.pl; p < p_end; p += q.lanes) {
         const long off = p * Cs + q.c0;
         Vec16<T> d, o, x;
         d.load(dz + off); x.load(y + off);
-        if (relu) o.load(z + off);
+        if (relu && !remask) o.load(z + off);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             float gk = d.v[k];
+            if (remask) o.v[k] = x.v[k] * sc[k] + sf[k];
             if (relu && !(o.v[k] > 0.f)) gk = 0.f;
             s1[k] += gk;
             s2[k] += gk * ((x.v[k] - mu[k]) * is[k]);
@@ -211,7 +215,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int ch
 template <typename T>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ z, const T* __restrict__ y,
                                                            const float* __restrict__ k1p, const float* __restrict__ k2p,
-                                                           const float* __restrict__ k3p, T* __restrict__ dy, T* __restrict__ dres,
+                                                           const float* __restrict__ k3p, const float* __restrict__ mscale,
+                                                           const float* __restrict__ mshift, T* __restrict__ dy, T* __restrict__ dres,
                                                            int dres_acc, long P, int C, int Cs, int relu, int iters) {
     constexpr int V = Vec16<T>::N;
     const Geo<T> q(Cs);
@@ -219,7 +224,10 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
     load_coef<V>(k1p, q.c0, C, k1, 0.f);
     load_coef<V>(k2p, q.c0, C, k2, 0.f);
     load_coef<V>(k3p, q.c0, C, k3, 0.f);
-    const bool need_y = (dy != nullptr) && (k2p != nullptr);
+    const bool remask = relu && z == nullptr;
+    float sc[V], sf[V];
+    if (remask) { load_coef<V>(mscale, q.c0, C, sc, 0.f); load_coef<V>(mshift, q.c0, C, sf, 0.f); }
+    const bool need_y = ((dy != nullptr) && (k2p != nullptr)) || remask;
     const long p0 = (long)blockIdx.x * q.lanes * iters + q.pl;
     for (int it = 0; it < iters; ++it) {
         const long p = p0 + (long)it * q.lanes;
@@ -228,14 +236,15 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
         Vec16<T> d, o, x, out, r;
         d.load(dz + off);
         if (need_y) x.load(y + off);
-        if (relu) o.load(z + off);
+        if (relu && !remask) o.load(z + off);
         if (dres && dres_acc) r.load(dres + off);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             float gk = d.v[k];
+            if (remask) o.v[k] = x.v[k] * sc[k] + sf[k];
             if (relu && !(o.v[k] > 0.f)) gk = 0.f;
             const bool live = q.c0 + k < C;
-            out.v[k] = live ? (k1[k] * gk + (need_y ? k2[k] * x.v[k] : 0.f) + k3[k]) : 0.f;
+            out.v[k] = live ? (k1[k] * gk + (k2p ? k2[k] * x.v[k] : 0.f) + k3[k]) : 0.f;
             if (dres) r.v[k] = (dres_acc ? r.v[k] : 0.f) + (live ? gk : 0.f);
         }
         if (dy) out.store(dy + off);
@@ -306,9 +315,9 @@ extern "C" int mpn_bn_bwd_chunks(int64_t P, int Cs, int dtype) {
 }
 
 extern "C" int mpn_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
-                                 float* partial, int chunks, int64_t P, int C, int Cs, int relu, int dtype, void* stream) {
+                                 const float* mask_scale, const float* mask_shift, float* partial, int chunks, int64_t P, int C, int Cs, int relu, int dtype, void* stream) {
     MPN_CHECK_ARG(dz && y && mean && invstd && partial && P > 0 && C > 0 && Cs >= C);
-    MPN_CHECK_ARG(!relu || z);
+    MPN_CHECK_ARG(!relu || z || (mask_scale && mask_shift && y));
     const int V = dtype == MPN_F32 ? 4 : 8;
     MPN_CHECK_ARG(geo_ok(Cs, V) && C % 4 == 0);
     const int chunk = reduce_chunk(P, geo_lanes(Cs, V));
@@ -316,10 +325,10 @@ extern "C" int mpn_bn_bwd_reduce(const void* dz, const void* z, const void* y, c
     dim3 grid((unsigned)chunks, (unsigned)geo_yblocks(Cs, V));
     if (dtype == MPN_F32)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, (const float*)z,
-                           (const float*)y, mean, invstd, partial, (long)P, C, Cs, relu, chunk);
+                           (const float*)y, mean, invstd, mask_scale, mask_shift, partial, (long)P, C, Cs, relu, chunk);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz, (const bf16_t*)z,
-                           (const bf16_t*)y, mean, invstd, partial, (long)P, C, Cs, relu, chunk);
+                           (const bf16_t*)y, mean, invstd, mask_scale, mask_shift, partial, (long)P, C, Cs, relu, chunk);
     return mpn_launch_status();
 }
 
@@ -333,21 +342,21 @@ extern "C" int mpn_bn_bwd_finalize(const float* partial, int chunks, int C, int6
 }
 
 extern "C" int mpn_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* k1, const float* k2, const float* k3,
-                                void* dy, void* dres, int dres_accumulate, int64_t P, int C, int Cs, int relu, int dtype,
+                                const float* mask_scale, const float* mask_shift, void* dy, void* dres, int dres_accumulate, int64_t P, int C, int Cs, int relu, int dtype,
                                 void* stream) {
     MPN_CHECK_ARG(dz && (dy || dres) && P > 0 && C > 0 && Cs >= C);
     MPN_CHECK_ARG(!dy || k1);
     MPN_CHECK_ARG(!(dy && k2) || y);
-    MPN_CHECK_ARG(!relu || z);
+    MPN_CHECK_ARG(!relu || z || (mask_scale && mask_shift && y));
     const int V = dtype == MPN_F32 ? 4 : 8;
     MPN_CHECK_ARG(geo_ok(Cs, V) && C % 4 == 0);
     const int lanes = geo_lanes(Cs, V), iters = pick_iters(P, lanes);
     dim3 grid((unsigned)((P + (long)lanes * iters - 1) / ((long)lanes * iters)), (unsigned)geo_yblocks(Cs, V));
     if (dtype == MPN_F32)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, (const float*)z,
-                           (const float*)y, k1, k2, k3, (float*)dy, (float*)dres, dres_accumulate, (long)P, C, Cs, relu, iters);
+                           (const float*)y, k1, k2, k3, mask_scale, mask_shift, (float*)dy, (float*)dres, dres_accumulate, (long)P, C, Cs, relu, iters);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz, (const bf16_t*)z,
-                           (const bf16_t*)y, k1, k2, k3, (bf16_t*)dy, (bf16_t*)dres, dres_accumulate, (long)P, C, Cs, relu, iters);
+                           (const bf16_t*)y, k1, k2, k3, mask_scale, mask_shift, (bf16_t*)dy, (bf16_t*)dres, dres_accumulate, (long)P, C, Cs, relu, iters);
     return mpn_launch_status();
 }

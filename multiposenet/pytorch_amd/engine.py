@@ -276,7 +276,7 @@ class Engine(object):
         dy = ops.bn_backward(dz, z, y, st, layer.weight.data, relu, train_stats,
                              dgamma=ar.grad_seg(layer.weight) if wg else None,
                              dbeta=ar.grad_seg(layer.bias) if bg else None,
-                             want_dy=want_dy, dres=dres, dres_acc=dres_acc)
+                             want_dy=want_dy, dres=dres, dres_acc=dres_acc, remask=bool(relu and res is None))
         if wg:
             self._grad_done(ctx, layer.weight)
         if bg:

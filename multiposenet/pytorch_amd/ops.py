@@ -329,8 +329,9 @@ def bn_act(y, st, relu, res=None, needs_grad=False, tag=""):
     return z
 
 
-def bn_backward(dz, z, y, st, gamma, relu, train, dgamma=None, dbeta=None, want_dy=True, dres=None, dres_acc=False):
-    """Returns dy (Act or None).  dres (Act) receives/accumulates g = dz*(z>0)."""
+def bn_backward(dz, z, y, st, gamma, relu, train, dgamma=None, dbeta=None, want_dy=True, dres=None, dres_acc=False, remask=False):
+    """Returns dy (Act or None).  dres (Act) receives/accumulates g = dz*(z>0).  remask=True (forward without a
+    residual input): the ReLU mask is recomputed from y and the forward's scale/shift instead of reading z."""
     dev = y.t.device
     P, C, Cs = y.P, y.C, y.Cs
     dc = dtype_code(y.t.dtype)
@@ -338,7 +339,8 @@ def bn_backward(dz, z, y, st, gamma, relu, train, dgamma=None, dbeta=None, want_
     if train or dgamma is not None or dbeta is not None:
         chunks = call("mpn_bn_bwd_chunks", P, Cs, dc)
         part = workspace(chunks * C * 2 * 4, dev, slot=3)
-        call("mpn_bn_bwd_reduce", ptr(dz.t), ptr(z.t) if relu else None, ptr(y.t), ptr(st.mean), ptr(st.invstd), ptr(part),
+        call("mpn_bn_bwd_reduce", ptr(dz.t), ptr(z.t) if (relu and not remask) else None, ptr(y.t), ptr(st.mean), ptr(st.invstd),
+             ptr(st.scale) if remask else None, ptr(st.shift) if remask else None, ptr(part),
              chunks, P, C, Cs, 1 if relu else 0, dc, stream_ptr())
         coef = torch.empty((3, C), dtype=torch.float32, device=dev) if train else None
         call("mpn_bn_bwd_finalize", ptr(part), chunks, C, P, ptr(gamma), ptr(st.mean), ptr(st.invstd), 1 if train else 0,
@@ -349,7 +351,8 @@ def bn_backward(dz, z, y, st, gamma, relu, train, dgamma=None, dbeta=None, want_
     if want_dy or dres is not None:
         if want_dy:
             dy = Act(torch.empty_like(y.t), C)
-        call("mpn_bn_bwd_apply", ptr(dz.t), ptr(z.t) if relu else None, ptr(y.t), ptr(k1), ptr(k2), ptr(k3),
+        call("mpn_bn_bwd_apply", ptr(dz.t), ptr(z.t) if (relu and not remask) else None, ptr(y.t), ptr(k1), ptr(k2), ptr(k3),
+             ptr(st.scale) if remask else None, ptr(st.shift) if remask else None,
              ptr(dy.t) if dy is not None else None, ptr(dres.t) if dres is not None else None,
              1 if dres_acc else 0, P, C, Cs, 1 if relu else 0, dc, stream_ptr())
     return dy

@@ -272,6 +272,11 @@ def test_batchnorm_train_and_eval(dtype, C):
         check_close("bn dbeta", db.cpu(), b_.grad, dtype, factor=f)
         if use_res:
             check_close("bn dres", from_act(dres), rl.grad, dtype)
+        if relu and not use_res:
+            # mask recomputed from y (no z read) must reproduce the z-based result bit for bit
+            dg2 = torch.zeros(C, device="cuda"); db2 = torch.zeros(C, device="cuda")
+            dy2 = ops.bn_backward(to_act(dz, dtype), za, ya, st, gamma.cuda(), relu, True, dgamma=dg2, dbeta=db2, remask=True)
+            assert torch.equal(dy2.t, dy.t) and torch.equal(dg2, dg) and torch.equal(db2, db), "remask path differs from z-mask path"
     # ---- eval / frozen
     yl = y.clone().requires_grad_(True)
     g_ = gamma.clone().requires_grad_(True); b_ = beta.clone().requires_grad_(True)
@@ -287,6 +292,9 @@ def test_batchnorm_train_and_eval(dtype, C):
     check_close("bn eval dy", from_act(dy), yl.grad, dtype)
     check_close("bn eval dgamma", dg.cpu(), g_.grad, dtype, factor=3)
     check_close("bn eval dbeta", db.cpu(), b_.grad, dtype, factor=3)
+    dg2 = torch.zeros(C, device="cuda"); db2 = torch.zeros(C, device="cuda")
+    dy2 = ops.bn_backward(to_act(dz, dtype), za, ya, st, gamma.cuda(), True, False, dgamma=dg2, dbeta=db2, remask=True)
+    assert torch.equal(dy2.t, dy.t) and torch.equal(dg2, dg) and torch.equal(db2, db), "frozen-BN remask path differs"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
