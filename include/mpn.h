@@ -73,6 +73,10 @@ typedef struct MpnWgradParams {
     int32_t R, S, stride, pad;
     int32_t dtype;
     int32_t chunks;       /* split of the B*Ho*Wo contraction; use mpn_conv_wgrad_chunks()        */
+    float* db;            /* optional bias gradient [Cout] f32, ACCUMULATED into: sum over pixels of dy.  Served
+                           * only by the bf16 LDS-DMA kernel (mpn_conv_wgrad_kernel_id & 1), where it costs one
+                           * extra MFMA against a vector of ones per dY fragment; otherwise must be NULL          */
+    float* db_ws;         /* workspace, >= chunks * Cout floats, when db != NULL and chunks > 1                    */
 } MpnWgradParams;
 
 int mpn_conv_wgrad_chunks(const MpnWgradParams* p);

@@ -46,6 +46,7 @@ class WgradParams(ctypes.Structure):
         ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32), ("Cout", ctypes.c_int32),
         ("R", ctypes.c_int32), ("S", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32),
         ("dtype", ctypes.c_int32), ("chunks", ctypes.c_int32),
+        ("db", ctypes.c_void_p), ("db_ws", ctypes.c_void_p),
     ]
 
 

@@ -420,6 +420,13 @@ __global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_kernel(c
         struct { s16x4_t a, b; } pr = {lo, hi};
         return __builtin_bit_cast(bf16x8_t, pr);
     };
+    // bias gradient = column sums of dY: the workgroups of the first cin tile / first tap multiply the dY fragments
+    // they hold anyway by a vector of ones (one extra MFMA per fragment in two of the four waves)
+    const bool do_bias = p.db != nullptr && tm == 0 && tap == 0 && wm == 0;
+    f32x4_t accb[MN];
+#pragma unroll
+    for (int j = 0; j < MN; ++j) accb[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bf16x8_t ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
     auto compute = [&](unsigned stage) {
         const unsigned char* la = lds + stage * STAGE_BYTES;
         const unsigned char* lb = la + A_BYTES;
@@ -433,6 +440,10 @@ __global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_kernel(c
 #pragma unroll
             for (int j = 0; j < MN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < MN; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fb[j], accb[j], 0, 0, 0);
+        }
     };
 
     const long span = k_end - k_begin;
@@ -455,6 +466,14 @@ __global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_kernel(c
     const long NW = (long)p.Cout * taps * p.Cin;
     float* __restrict__ dst = (p.chunks > 1) ? (p.ws + (long)chunk * NW) : p.dw;
     const bool add = (p.chunks == 1);
+    if (do_bias && lane < 16) {                 // every row of the ones-product holds the column sum: row 0 = lanes 0..15, reg 0
+        float* __restrict__ bdst = (p.chunks > 1) ? (p.db_ws + (long)chunk * p.Cout) : p.db;
+#pragma unroll
+        for (int j = 0; j < MN; ++j) {
+            const int cout = n0 + wn * (TN / 2) + j * 16 + lane;
+            if (cout < p.Cout) bdst[cout] = (add ? bdst[cout] : 0.f) + accb[j][0];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MM; ++i) {
         const int cin = m0 + wm * (TM / 2) + i * 16 + (lane >> 4) * 4;
@@ -582,6 +601,12 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st, bool reduce = true) {
     else rc = launch_wgrad_n<T, 32>(p, tn, grid, chunk_pixels, st);
     if (rc != 0) return rc;
     if (p.chunks > 1 && reduce) {
+        if (p.db) {
+            hipLaunchKernelGGL(reduce_partials_small_kernel, dim3((unsigned)((p.Cout + 15) / 16)), dim3(256), 0, st,
+                               (const float*)p.db_ws, p.chunks, (long)p.Cout, p.db, 1);
+            rc = mpn_launch_status();
+            if (rc != 0) return rc;
+        }
         rc = launch_reduce_partials((const float*)p.ws, p.chunks, (long)p.Cout * p.R * p.S * p.Cin, p.dw, 1, st);
     }
     return rc;
@@ -613,6 +638,7 @@ extern "C" int mpn_conv_wgrad(const MpnWgradParams* pp, void* stream) {
     MPN_CHECK_ARG(p.B > 0 && p.Ho > 0 && p.Wo > 0 && p.Cin > 0 && p.Cout > 0);
     MPN_CHECK_ARG(p.Cin % 8 == 0);
     MPN_CHECK_ARG(p.chunks >= 1 && (p.chunks == 1 || p.ws));
+    MPN_CHECK_ARG(!p.db || (wgrad_uses_dma(p) && (p.chunks == 1 || p.db_ws)));
     hipStream_t st = (hipStream_t)stream;
     if (p.dtype == MPN_F32) return launch_wgrad<float>(p, st);
     return launch_wgrad<bf16_t>(p, st);

@@ -227,9 +227,11 @@ class Engine(object):
         bg = bias is not None and bias.requires_grad
         if wg or bg:
             def param_grads():
-                if wg:
-                    ops.conv_wgrad(x, dy, ar.grad_seg(layer.weight), O, R, S, stride, pad)
-                if bg:
+                done = False
+                if wg:           # the bias gradient rides along in the wgrad kernel where the LDS-DMA path serves it
+                    done = ops.conv_wgrad(x, dy, ar.grad_seg(layer.weight), O, R, S, stride, pad,
+                                          db=ar.grad_seg(bias) if bg else None)
+                if bg and not done:
                     ops.bias_grad(dy, ar.grad_seg(bias), O)
             self._on_side(ctx, dy.t.device, (x, dy), param_grads)
             if wg:

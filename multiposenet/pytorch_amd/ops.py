@@ -232,8 +232,9 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
     return out, stats
 
 
-def conv_wgrad(x, dy, dw, Cout, R, S, stride, pad, cin=None, x_geom=None):
-    """dw (f32 view laid out [Cout][R][S][Cin], contiguous) += wgrad(x, dy)."""
+def conv_wgrad(x, dy, dw, Cout, R, S, stride, pad, cin=None, x_geom=None, db=None):
+    """dw (f32 view laid out [Cout][R][S][Cin], contiguous) += wgrad(x, dy).  db (f32 [Cout], optional) += column sums of
+    dy, fused into the same kernel where the LDS-DMA path serves the launch; returns True if db was taken care of."""
     dev = x.t.device
     dt = x.t.dtype
     p = WgradParams()
@@ -257,6 +258,12 @@ def conv_wgrad(x, dy, dw, Cout, R, S, stride, pad, cin=None, x_geom=None):
     if chunks > 1:
         ws = workspace(chunks * Cout * R * S * Cin * 4, dev, slot=1)
         p.ws = ws.data_ptr()
+    fused_db = False
+    if db is not None and (call("mpn_conv_wgrad_kernel_id", ctypes.byref(p)) & 1):
+        fused_db = True
+        p.db = db.data_ptr()
+        if chunks > 1:
+            p.db_ws = workspace(chunks * Cout * 4, dev, slot=4).data_ptr()
     if KERNEL_EVENTS.on:
         # bracket the MFMA kernel alone (the partial-sum reduction is launched separately) so the class time
         # matches the kernel's own row in a rocprofv3 trace
@@ -273,8 +280,11 @@ def conv_wgrad(x, dy, dw, Cout, R, S, stride, pad, cin=None, x_geom=None):
         KERNEL_EVENTS.end(name, 2.0 * x.B * dy.H * dy.W * Cout * R * S * Cin, e0)
         if chunks > 1:
             call("mpn_reduce_partials", p.ws, chunks, Cout * R * S * Cin, p.dw, 1, stream_ptr())
+            if fused_db:
+                call("mpn_reduce_partials", p.db_ws, chunks, Cout, p.db, 1, stream_ptr())
     else:
         call("mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
+    return fused_db
 
 
 def bias_grad(dy, db, C):

@@ -194,6 +194,18 @@ def test_wgrad_partials_entry_point_matches_fused_call():
             ops.KERNEL_EVENTS.disable()
         assert torch.equal(dw, dw2)
         assert names and names[0].startswith("conv_wgrad_dma_kernel<"), names
+        # bias gradient fused into the same kernel (ones-vector MFMA): sliced and bracketed paths, vs the column sums
+        for events in (False, True):
+            dw3 = torch.zeros_like(dw)
+            db = torch.full((Cout,), 0.5, dtype=torch.float32, device="cuda")
+            if events:
+                ops.KERNEL_EVENTS.enable()
+            try:
+                assert ops.conv_wgrad(to_act(x, dtype), to_act(dy, dtype), dw3, Cout, 1, 1, 1, 0, db=db) is True
+            finally:
+                ops.KERNEL_EVENTS.disable()
+            assert torch.equal(dw3, dw)
+            check_close("fused bias grad %dx%d" % (Cin, Cout), db.cpu() - 0.5, dy.float().cpu().sum((0, 2, 3)), torch.float32, factor=5)
         ref = torch.einsum("bohw,bihw->oi", dy.float().cpu(), x.float().cpu())
         check_close("wgrad dma tile %dx%d" % (Cin, Cout), dw.cpu().view(Cout, Cin), ref, dtype)
 
