@@ -405,3 +405,51 @@ def test_loss_log_is_plain_floats_by_default_and_lazy_on_request():
         assert isinstance(v, numbers.Real) and not isinstance(v, float)
         assert float(v) == eager[k] and v == eager[k] and v * 2 == eager[k] * 2 and 1 + v == 1 + eager[k]
         assert "{:.10f}".format(v) == "{:.10f}".format(eager[k]) and repr(v) == repr(eager[k])
+
+
+def test_cfg4_large_resolution_training_step_properties():
+    """SURVEY 8d cfg4 shape class (R101 full posenet, 800x800, the upsample/concat stress): a train step at the full
+    resolution (2 images) runs through every tile variant (256-row igemm tiles, sliced wgrad at 200x200), gives finite
+    losses/gradients, and is bit-reproducible."""
+    from oracle import weightgen
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    m = get_model(101, torch.bfloat16)
+    m.train()
+    B, S = 2, 800
+    img = t(weightgen.gen_images(21, B, S, S)).cuda()
+    heat, wgt = (t(a).cuda() for a in weightgen.gen_keypoint_gt(22, B, S // 4, S // 4))
+    anno = t(weightgen.gen_boxes_gt(23, B, S)).cuda()
+    bn_state = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
+    outs = []
+    for _ in range(2):
+        m.load_state_dict(bn_state, strict=False)
+        m._arena.ensure_grads()
+        m._arena.grad_flat.zero_()
+        pred, (ks, ds) = m([img, "train_both"])
+        assert pred.shape == (B, 18, 200, 200) and ds[0].shape == (B, 120087, 1)          # A = 120 087 anchors at 800^2
+        loss, log = poseNet.build_loss((ks, ds), "train_both", heat, wgt, anno)
+        loss.backward()
+        torch.cuda.synchronize()
+        outs.append((loss.detach().clone(), m._arena.grad_flat.clone()))
+    assert torch.isfinite(outs[0][0]) and torch.isfinite(outs[0][1]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    report("cfg4 shape (R101 800x800 B=2 bf16): train step finite and bit-reproducible, loss %.4f" % outs[0][0].item())
+
+
+def test_cfg5_inference_640_all_images_properties():
+    """SURVEY 8d cfg5 shape class (R101 'both' inference at 640x640, A = 76 725 anchors): whole-batch inference equals
+    the per-image reference semantics, boxes are inside the image, scores sorted and above the 0.05 threshold."""
+    from oracle import weightgen
+    m = get_model(101, torch.bfloat16)
+    m.eval()
+    img = t(weightgen.gen_images(31, 4, 640, 640)).cuda()
+    with torch.no_grad():
+        heat, dets = m.forward_all_images(img)
+        assert heat.shape == (4, 18, 160, 160) and len(dets) == 4
+        h1, d1 = m([img[2:3].contiguous(), "both"])
+    assert torch.equal(h1, heat[2:3])
+    assert torch.equal(d1[0], dets[2][0]) and torch.equal(d1[2], dets[2][2])
+    for scores, cls_idx, boxes in dets:
+        if scores.numel():
+            assert float(scores.min()) > 0.05 and bool((scores[:-1] >= scores[1:]).all())
+            assert float(boxes.min()) >= 0.0 and float(boxes.max()) <= 640.0
