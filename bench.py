@@ -270,7 +270,7 @@ def main():
         ms = elapsed / args.steps * 1000.0
         ips = args.batch * world * args.steps / elapsed
         out = {
-            "metric": "images/sec (train fwd+bwd) ResNet101 480x480 bs=32/GPU",
+            "metric": "images/sec (train fwd+bwd) ResNet%d %dx%d bs=%d/GPU" % (args.layers, args.size, args.size, args.batch),
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
