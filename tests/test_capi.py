@@ -88,3 +88,43 @@ def test_product_never_imports_the_oracle():
                 assert "oracle" not in txt.replace("the CPU oracle", "").replace("CPU oracle's", "") or f.endswith(".hip"), \
                     "%s mentions the oracle" % os.path.join(dp, f)
                 assert "import oracle" not in txt and "from oracle" not in txt
+
+
+def test_entry_points_reject_bad_arguments_without_touching_the_gpu():
+    """Error behaviour of the C ABI (compare SURVEY.md 8b: the reference's cffi functions return 1 always and never
+    check anything): null pointers and nonsensical sizes come back as MPN_E_BADARG before any HIP call is made, so this
+    runs on a machine without a GPU."""
+    import ctypes
+    from multiposenet.pytorch_amd import _lib
+    from multiposenet.pytorch_amd._lib import ConvParams, WgradParams
+    L = _lib.lib()
+    BAD = -1
+    src = open(os.path.join(ROOT, "include", "mpn.h")).read()
+    m = re.search(r"#define\s+MPN_E_BADARG\s+\(?(-?\d+)\)?", src)
+    if m:
+        BAD = int(m.group(1))
+    nul = ctypes.c_void_p(None)
+    one = ctypes.c_void_p(0x1000)            # never dereferenced: validation fails first
+    assert L.mpn_conv_forward(None, nul) == BAD
+    assert L.mpn_conv_wgrad(None, nul) == BAD
+    assert L.mpn_conv_wgrad_partials(None, nul) == BAD
+    p = ConvParams()                          # all-zero struct: null tensors
+    assert L.mpn_conv_forward(ctypes.byref(p), nul) == BAD
+    p.x, p.w, p.y = 0x1000, 0x1000, 0x1000
+    p.B, p.H, p.W, p.Ho, p.Wo, p.Cin, p.Cout, p.Cout_store, p.R, p.S, p.stride = 1, 8, 8, 8, 8, 30, 8, 8, 3, 3, 1
+    p.dtype = 1
+    assert L.mpn_conv_forward(ctypes.byref(p), nul) == BAD            # Cin not a multiple of the 64-byte K chunk
+    w = WgradParams()
+    assert L.mpn_conv_wgrad(ctypes.byref(w), nul) == BAD
+    assert L.mpn_reduce_partials(nul, 4, 16, one, 1, nul) == BAD
+    assert L.mpn_reduce_partials(one, 0, 16, one, 1, nul) == BAD
+    assert L.mpn_weight_transpose(nul, one, 8, 1, 8, 8, 1, nul) == BAD
+    assert L.mpn_weight_transpose(one, one, 8, 1, 8, 4, 1, nul) == BAD    # Cout_pad < Cout
+    assert L.mpn_weight_transpose_batched(one, one, nul, 3, 10, 1, nul) == BAD
+    assert L.mpn_bn_act_forward(nul, nul, one, one, one, 16, 8, 8, 1, 1, nul) == BAD
+    assert L.mpn_bn_bwd_reduce(one, nul, one, one, one, nul, nul, one, 1, 16, 32, 32, 1, 1, nul) == BAD   # relu without z or mask coefficients
+    assert L.mpn_gt_heatmaps(nul, one, 1, 1, one, 4, 4, 4.0, 7.0, nul) == BAD
+    assert L.mpn_gt_heatmaps(one, one, 1, 1, one, 4, 4, 0.0, 7.0, nul) == BAD
+    assert L.mpn_heatmap_peaks(one, 0, 0, 0, 0, 1, 18, 0, 8, 0.1, 4.0, 1, one, one, 16, nul) == BAD
+    assert L.mpn_heatmap_peaks(one, 0, 0, 0, 0, 1, 18, 8, 8, 0.1, 4.0, 1, one, one, 0, nul) == BAD       # cap == 0
+    assert L.mpn_nms(nul, 4, 0.5, 0, one, one, one, nul) != 0
