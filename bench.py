@@ -7,13 +7,19 @@ bf16 MFMA arithmetic with fp32 accumulation and fp32 master weights, synthetic C
 resident in HBM.  One process per GPU; N>1 = data parallel (RCCL all-reduce of the flat gradient
 arena overlapped with backward); weak scaling (32 images per GPU).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the 128x128 bf16 implicit-GEMM
-conv tile), timed live with HIP events on the launch stream during the timed steps; `cpu_baseline`
-is the oracle's torch-CPU restatement of the same step timed on this host (rank 0, N=1 only).
+The timed step is ONE hipGraph launch (multiposenet/pytorch_amd/graph.py: forward, losses, zero_grad, backward on two
+HIP streams, RCCL buckets, Adam — captured once, replayed per step; `--no-graph` times the eager tape).  Every timed
+step is also bracketed by a pair of HIP events on the launch stream; their median is reported beside the wall-clock
+mean that `value` is computed from.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel class, timed with HIP events on the launch stream
+in separate instrumented eager steps AFTER the timed region, one kernel on the GPU at a time (top level); the same
+brackets with the weight-gradient side stream on are nested under `overlapped`.  `cpu_baseline` is the oracle's
+torch-CPU restatement of the same step timed on this host (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -37,8 +43,8 @@ PEAK_F32_TFLOPS = 157.3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--size", type=int, default=480)
     ap.add_argument("--layers", type=int, default=101)
@@ -46,7 +52,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--eager-log", action="store_true", help="plain-float loss logs (one host sync per step, the reference's behaviour)")
-    ap.add_argument("--event-every", type=int, default=8, help="bracket conv launches with HIP events on every n-th timed step")
+    ap.add_argument("--no-graph", action="store_true", help="time the eager Python tape instead of the captured hipGraph")
+    ap.add_argument("--instr-steps", type=int, default=2, help="instrumented eager steps per schedule after the timed region")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and the gradient reducer even with one rank")
@@ -156,15 +163,15 @@ def pmc_traffic(kernel_class):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
     if not files:
-        return None
+        return None, None
     try:
         prof = json.load(open(files[-1]))
         for k in prof["kernels"]:
             if k["kernel"] == kernel_class:
-                return int(k["hbm_bytes_per_launch"])
-        return None
+                return int(k["hbm_bytes_per_launch"]), "%s (library build %s)" % (os.path.basename(files[-1]), prof.get("build_id", "unrecorded"))
+        return None, None
     except Exception:
-        return None
+        return None, None
 
 
 def main():
@@ -213,58 +220,73 @@ def main():
     img, heat, wgt, anno = synth(args.batch, args.size, dev, seed=100 + rank)
 
     last_log = {}
+    from multiposenet.pytorch_amd.graph import GraphedTrainStep
+    from multiposenet.pytorch_amd.training.batch_processor import train_step
+    inputs, gts = [[img, "train_both"]], ["train_both", heat, wgt, anno]
+    gstep = None if args.no_graph else GraphedTrainStep(model, opt)
 
     def step():
-        pred, (ks, ds) = model([img, "train_both"])
-        loss, log = poseNet.build_loss((ks, ds), "train_both", heat, wgt, anno)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
+        loss, log = gstep(inputs, gts) if gstep is not None else train_step(model, opt, inputs, gts)
         last_log["log"] = log
         return loss
 
+    if gstep is not None:
+        # set-up, not warm-up: the eager passes that fill host-side caches, then the capture + first replay (the
+        # equivalent of compiling); the W warm-up steps below are replays like the timed ones
+        for _ in range(gstep.eager_steps + 1):
+            step()
     for _ in range(args.warmup):
         step()
-    # Per-launch HIP events serialise neighbouring kernels (~3 us per bracket, ~3 ms/step if every conv launch of
-    # every step is bracketed), so only every `--event-every`-th step of the timed region is instrumented.
-    ev_every = 0 if args.no_kernel_events else min(max(1, args.event_every), max(1, args.steps))
-    ev_steps = 0
-    ops.KERNEL_EVENTS.enable()
-    ops.KERNEL_EVENTS.disable()                # clears the record list
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
-        if ev_every and i % ev_every == ev_every - 1:
-            ops.KERNEL_EVENTS.on = True
-            ev_steps += 1
         loss = step()
-        ops.KERNEL_EVENTS.on = False
+        marks[i + 1].record()
     t_enq = time.perf_counter() - t0             # host time to enqueue the K steps (the GPU may still be running)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    ops.KERNEL_EVENTS.disable()
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(loss).all()
-    ke = ops.KERNEL_EVENTS.summary()
-    # kernel quality in isolation: the same instrumented step with the weight-gradient side stream switched off
-    ke_serial, serial_steps = {}, 0
-    if ke and model._engine.overlap_wgrad:
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+
+    # Kernel-level roofline: instrumented EAGER steps outside the timed region (per-launch event brackets serialise
+    # neighbouring kernels, and events cannot be read out of a graph replay).  First with the weight-gradient side
+    # stream off (one kernel on the GPU at a time: the kernel's own quality, comparable with a serial rocprofv3 trace),
+    # then with the production schedule (brackets time-share the GPU with the other stream).
+    ke, ke_serial, ev_steps, serial_steps = {}, {}, 0, 0
+    if not args.no_kernel_events:
+        def eager():
+            return train_step(model, opt, inputs, gts)[0]
+        overlap = model._engine.overlap_wgrad
         model._engine.overlap_wgrad = False
+        eager()                                   # untimed: workspaces of the eager streams
         ops.KERNEL_EVENTS.enable()
-        serial_steps = 2
+        serial_steps = max(1, args.instr_steps)
         for _ in range(serial_steps):
-            step()
+            eager()
         torch.cuda.synchronize()
         ops.KERNEL_EVENTS.disable()
         ke_serial = ops.KERNEL_EVENTS.summary()
-        model._engine.overlap_wgrad = True
+        model._engine.overlap_wgrad = overlap
+        if overlap:
+            eager()
+            ops.KERNEL_EVENTS.enable()
+            ev_steps = max(1, args.instr_steps)
+            for _ in range(ev_steps):
+                eager()
+            torch.cuda.synchronize()
+            ops.KERNEL_EVENTS.disable()
+            ke = ops.KERNEL_EVENTS.summary()
 
     if rank == 0:
         ms = elapsed / args.steps * 1000.0
@@ -278,33 +300,36 @@ def main():
                                    "%dx%d, %d images/GPU, %s MFMA / fp32 accumulate / fp32 master weights"
                                    % (args.layers, args.size, args.size, args.batch, args.dtype),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "loss_log": "eager floats (host sync per step)" if args.eager_log else "asynchronous (set_lazy_log)"},
+                       "loss_log": "eager floats (host sync per step)" if args.eager_log else "asynchronous (set_lazy_log)",
+                       "launch": "eager tape" if gstep is None else "one hipGraph replay per step (%d replays so far)" % gstep.replays},
         }
+        out["ms_per_step_median_hipevent"] = round(median_ms, 3)
+        out["ms_per_step_min_max_hipevent"] = [round(step_ms[0], 3), round(step_ms[-1], 3)]
         out["last_step_log"] = {k: round(float(v), 6) for k, v in last_log["log"].items()      # values exist, they were just
                                 if k in ("heatmap_loss", "total_loss", "classification_loss", "regression_loss")}   # not waited for
         out["host_enqueue_ms_per_step"] = round(t_enq / args.steps * 1000.0, 3)
         gf = GFLOP_PER_IMG_TRAIN.get(("r%d" % args.layers, args.size))
         if gf is not None:
             out["model_tflops_per_gpu"] = round(ips / world * gf / 1000.0, 2)
-        if ke:
+        if ke_serial:
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-            dom = max(ke.items(), key=lambda kv: kv[1]["ms"])
-            name, d = dom
+            name, d = max(ke_serial.items(), key=lambda kv: kv[1]["ms"])
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+            traffic, traffic_src = pmc_traffic(name)
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(ach / peak, 4), "traffic": pmc_traffic(name), "launches": d["n"],
-                               "avg_launch_us": round(d["ms"] * 1000.0 / max(d["n"], 1), 2),
-                               "share_of_step": round(d["ms"] / (ms * ev_steps), 4), "instrumented_steps": ev_steps,
-                               "note": "durations bracketed in the timed region, where weight-gradient launches share the GPU "
-                                       "with the dgrad/BN chain of the main stream (time-sliced, so longer than in isolation)"}
-            ds = ke_serial.get(name)
-            if ds and ds["ms"] > 0:
-                ach_s = ds["flops"] / (ds["ms"] * 1e-3) / 1e12
-                out["roofline"]["isolated"] = {"achieved": round(ach_s, 2), "frac": round(ach_s / peak, 4),
-                                               "avg_launch_us": round(ds["ms"] * 1000.0 / max(ds["n"], 1), 2), "launches": ds["n"],
-                                               "how": "same kernel, %d extra steps after the timed region with the side stream off "
-                                                      "(MPN_SIDE_STREAM=0 behaviour: one kernel on the GPU at a time)" % serial_steps}
-            out["kernel_classes_ms_per_step"] = {k: round(v["ms"] / ev_steps, 3) for k, v in sorted(ke.items(), key=lambda kv: -kv[1]["ms"])}
+                               "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                               "launches": d["n"], "avg_launch_us": round(d["ms"] * 1000.0 / max(d["n"], 1), 2),
+                               "instrumented_steps": serial_steps,
+                               "how": "HIP events around every launch of the class in %d eager steps after the timed region, weight-gradient "
+                                      "side stream off (one kernel on the GPU at a time; comparable with a serial rocprofv3 trace)" % serial_steps}
+            do = ke.get(name)
+            if do and do["ms"] > 0:
+                ach_o = do["flops"] / (do["ms"] * 1e-3) / 1e12
+                out["roofline"]["overlapped"] = {"achieved": round(ach_o, 2), "frac": round(ach_o / peak, 4),
+                                                 "avg_launch_us": round(do["ms"] * 1000.0 / max(do["n"], 1), 2), "launches": do["n"],
+                                                 "how": "same brackets with the production two-stream schedule: the launch time-shares "
+                                                        "the GPU with the other stream, so it reads longer than in isolation"}
+            out["kernel_classes_ms_per_step"] = {k: round(v["ms"] / serial_steps, 3) for k, v in sorted(ke_serial.items(), key=lambda kv: -kv[1]["ms"])}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         sys.stdout.flush()

@@ -9,7 +9,7 @@
  * Tensor model: activations are NHWC ("pixel-major"): element (b, h, w, c) of a tensor lives at
  *     base + b*sB + (h*W + w)*sP + c            (strides in ELEMENTS, channel stride 1)
  * Internal tensors keep their channel count padded to a multiple of 32 (pad lanes hold zeros) so
- * every 64-byte K-chunk load is in bounds and 16-byte aligned.  dtype codes: 0 = f32, 1 = bf16.
+ * every 64-byte K-chunk load is in bounds and 16-byte aligned.  dtype codes: 0 = f32, 1 = bf16, 2 = f16.
  *
  * Each entry point cites the reference interface it replaces (paths relative to the reference).
  */
@@ -23,6 +23,7 @@ extern "C" {
 
 #define MPN_F32 0
 #define MPN_BF16 1
+#define MPN_F16 2      /* IEEE half: same kernels, v_mfma_f32_16x16x32_f16 (BASELINE config 5 inference arithmetic) */
 
 #define MPN_E_BADARG (-2)
 #define MPN_E_UNSUPPORTED (-3)
@@ -94,6 +95,8 @@ int mpn_reduce_partials(const float* ws, int chunks, int64_t n, float* dst, int 
  * Parameter preparation (once per step): master f32 [Cout][R][S][Cin] -> compute-dtype copies.
  * -------------------------------------------------------------------------------------------*/
 int mpn_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* same for either 16-bit type (dtype = MPN_BF16 or MPN_F16) */
+int mpn_cast_f32(const float* src, void* dst, int64_t n, int dtype, void* stream);
 /* Wt[ci][r][s][co_pad] = W[co][r][s][ci] (co >= Cout -> 0); ci_pad rows beyond Cin are zero too */
 int mpn_weight_transpose(const float* w, void* wt, int Cout, int RS, int Cin, int Cout_pad,
                          int dtype, void* stream);
@@ -200,9 +203,10 @@ int mpn_sigmoid_forward(const float* x, float* y, int64_t n, void* stream);   /*
 /* dlogit = dp * p * (1-p) */
 int mpn_sigmoid_backward(const float* dp, const float* p, float* dlogit, int64_t n, void* stream);
 /* PRN: out = softmax(relu?(a) + res) rowwise (posenet.py:345-347); BCE mean (posenet.py:436-439) */
-int mpn_add_softmax_rows(const float* a, const float* res, float* out, int rows, int cols, int relu, void* stream);
-/* dlogit = p*(dp - sum p*dp), masked by pre_relu > 0 when pre_relu != NULL */
-int mpn_softmax_rows_backward(const float* p, const float* dp, const float* pre_relu, float* dlogit, int rows, int cols, void* stream);
+int mpn_add_softmax_rows(const float* a, int64_t a_stride, const float* res, float* out, int rows, int cols, int relu, void* stream);
+/* dlogit = p*(dp - sum p*dp), masked by pre_relu > 0 when pre_relu != NULL.  a / pre_relu: rows of `cols` values with row
+ * stride a_stride / pre_stride (the conv output they come from is padded to a multiple of 32 columns) */
+int mpn_softmax_rows_backward(const float* p, const float* dp, const float* pre_relu, int64_t pre_stride, float* dlogit, int rows, int cols, void* stream);
 int mpn_bce_mean_backward(const float* p, const float* label, float* dp, int64_t n, const float* gscale, void* stream);
 /* nn.Dropout (posenet.py:139,341-342): y = keep(seed, i) ? x / (1 - p) : 0, counter-based (same call with the same seed
  * applied to a gradient is the backward) */
@@ -222,8 +226,18 @@ int mpn_clip_boxes(float* boxes, int64_t n, float img_w, float img_h, void* stre
 int mpn_score_filter(const float* boxes, const float* scores, int A, float thresh, float* dets,
                      int32_t* src_idx, int32_t* count, void* stream);
 
+/* the same for every image of a batch in one launch (BASELINE config 5: batch 64; the reference thresholds image 0 only,
+ * posenet.py:271): boxes [B,A,4], scores [B,A]; image b's candidates go to dets[b*A*5 ...] (order preserved),
+ * src_idx[b*A ...] (optional), counts[b]. */
+int mpn_score_filter_batched(const float* boxes, const float* scores, int B, int A, float thresh, float* dets,
+                             int32_t* src_idx, int32_t* counts, void* stream);
+
 /* boxes[k,4], scores[k] = rows keep[0..k) of dets[n,5] */
 int mpn_gather_dets(const float* dets, const int64_t* keep, int k, float* boxes, float* scores, void* stream);
+/* per image b < B: boxes[b*out_stride*4 ...], scores[b*out_stride ...] = rows keep[b*keep_stride + (0..num[b])) of the
+ * image's candidate block dets + b*dets_stride (floats); kmax >= max num[b] sizes the launch */
+int mpn_gather_dets_batched(const float* dets, int64_t dets_stride, const int64_t* keep, int64_t keep_stride, const int64_t* num,
+                            int B, int kmax, float* boxes, float* scores, int64_t out_stride, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * NMS — replaces lib/nms: gpu_nms (src/nms_cuda.c:17-67), _nms/nms_kernel
@@ -236,6 +250,13 @@ int mpn_gather_dets(const float* dets, const int64_t* keep, int k, float* boxes,
 int64_t mpn_nms_workspace_bytes(int64_t n);
 int mpn_nms(const float* dets, int64_t n, float thresh, int mode, int64_t* keep_out, int64_t* num_out,
             void* workspace, void* stream);
+/* Segmented NMS: B independent problems in the same three launches, sizes read ON THE DEVICE (counts[b] candidates for
+ * image b, rows at dets + b*dets_stride floats), so a batch needs no per-image host round trip.  nmax >= max counts[b]
+ * sizes the launches and the workspace (mpn_nms_batched_workspace_bytes(B, nmax)); keep_out [B][keep_stride] i64,
+ * num_out [B] i64.  Each image's result equals mpn_nms on that image alone. */
+int64_t mpn_nms_batched_workspace_bytes(int B, int64_t nmax);
+int mpn_nms_batched(const float* dets, int64_t dets_stride, const int32_t* counts, int B, int64_t nmax, float thresh, int mode,
+                    int64_t* keep_out, int64_t keep_stride, int64_t* num_out, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer: torch.optim.Adam semantics (training/multipose_keypoint_train.py:106-110), fused over
@@ -244,6 +265,14 @@ int mpn_nms(const float* dets, int64_t n, float thresh, int mode, int64_t* keep_
 int mpn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay,
                   float bias_correction1, float bias_correction2_sqrt, float grad_scale, void* stream);
+/* The same update with every scalar read from DEVICE memory, so that a captured hipGraph of the training step replays
+ * correct Adam steps: hyper[0..7] = {lr, beta1, beta2, eps, weight_decay, grad_scale, bias_correction1,
+ * sqrt(bias_correction2)} (floats), hyper[8] = step count (int32 bits).  mpn_adam_advance does step += 1 and recomputes
+ * hyper[6..7] (double-precision pow, the values torch computes on the host); mpn_adam_step_dev applies one update to a
+ * 16-byte aligned run of the arena.  The host only rewrites hyper[0] when the scheduler changes the learning rate. */
+int mpn_adam_advance(float* hyper, void* stream);
+int mpn_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper,
+                      void* stream);
 int mpn_fill_f32(float* dst, float v, int64_t n, void* stream);
 
 /* library self-description */

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmpn_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 
 
 class MpnError(RuntimeError):
@@ -68,6 +68,7 @@ SIGNATURES = {
     "mpn_conv_wgrad_kernel_id": (_i, [_PW]),
     "mpn_reduce_partials": (_i, [_vp, _i, _i64, _vp, _i, _vp]),
     "mpn_cast_f32_to_bf16": (_i, [_vp, _vp, _i64, _vp]),
+    "mpn_cast_f32": (_i, [_vp, _vp, _i64, _i, _vp]),
     "mpn_weight_transpose": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mpn_weight_transpose_batched": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp]),
     "mpn_weight_pad_k": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -106,8 +107,8 @@ SIGNATURES = {
     "mpn_sigmoid_forward": (_i, [_vp, _vp, _i64, _vp]),
     "mpn_gather_dets": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "mpn_sigmoid_backward": (_i, [_vp, _vp, _vp, _i64, _vp]),
-    "mpn_add_softmax_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
-    "mpn_softmax_rows_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mpn_add_softmax_rows": (_i, [_vp, _i64, _vp, _vp, _i, _i, _i, _vp]),
+    "mpn_softmax_rows_backward": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _vp]),
     "mpn_bce_mean_backward": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "mpn_dropout": (_i, [_vp, _vp, _i64, ctypes.c_uint64, _f, _i, _vp]),
     "mpn_bce_chunks": (_i, [_i64]),
@@ -115,16 +116,22 @@ SIGNATURES = {
     "mpn_box_decode_clip": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),
     "mpn_clip_boxes": (_i, [_vp, _i64, _f, _f, _vp]),
     "mpn_score_filter": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    "mpn_score_filter_batched": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "mpn_gather_dets_batched": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _vp, _i64, _vp]),
+    "mpn_nms_batched_workspace_bytes": (_i64, [_i, _i64]),
+    "mpn_nms_batched": (_i, [_vp, _i64, _vp, _i, _i64, _f, _i, _vp, _i64, _vp, _vp, _vp]),
     "mpn_nms_workspace_bytes": (_i64, [_i64]),
     "mpn_nms": (_i, [_vp, _i64, _f, _i, _vp, _vp, _vp, _vp]),
     "mpn_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _f, _vp]),
+    "mpn_adam_advance": (_i, [_vp, _vp]),
+    "mpn_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "mpn_fill_f32": (_i, [_vp, _f, _i64, _vp]),
     "mpn_version": (ctypes.c_char_p, []),
 }
 
 # entry points that return a count, not a status
 _COUNT_FUNCS = {"mpn_conv_stats_tiles", "mpn_conv_tile_rows", "mpn_conv_wgrad_chunks", "mpn_conv_wgrad_kernel_id", "mpn_bn_bwd_chunks", "mpn_channel_sum_chunks",
-                "mpn_mse_chunks", "mpn_focal_blocks", "mpn_bce_chunks", "mpn_nms_workspace_bytes", "mpn_version"}
+                "mpn_mse_chunks", "mpn_focal_blocks", "mpn_bce_chunks", "mpn_nms_workspace_bytes", "mpn_nms_batched_workspace_bytes", "mpn_version"}
 
 _lib = None
 

@@ -40,7 +40,7 @@ class ParamArena(object):
                 p.data = v
                 p.grad = None
                 self.index[id(p)] = i
-        self.bf16 = None
+        self.lowp = {}          # 16-bit operand copies of the whole arena, by dtype (refreshed once per forward)
 
     def _view(self, flat, i, shape):
         seg = flat[self.offsets[i]: self.offsets[i] + self.sizes[i]]

@@ -298,12 +298,8 @@ extern "C" int mpn_bn_act_forward(const void* y, const void* res, void* z, const
     MPN_CHECK_ARG(geo_ok(Cs, V) && C % 4 == 0);
     const int lanes = geo_lanes(Cs, V), iters = pick_iters(P, lanes);
     dim3 grid((unsigned)((P + (long)lanes * iters - 1) / ((long)lanes * iters)), (unsigned)geo_yblocks(Cs, V));
-    if (dtype == MPN_F32)
-        hipLaunchKernelGGL(bn_act_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, (const float*)res, (float*)z,
-                           scale, shift, (long)P, C, Cs, relu, iters);
-    else
-        hipLaunchKernelGGL(bn_act_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (const bf16_t*)res,
-                           (bf16_t*)z, scale, shift, (long)P, C, Cs, relu, iters);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)y, (const T*)res,
+                           (T*)z, scale, shift, (long)P, C, Cs, relu, iters));
     return mpn_launch_status();
 }
 
@@ -323,12 +319,8 @@ extern "C" int mpn_bn_bwd_reduce(const void* dz, const void* z, const void* y, c
     const int chunk = reduce_chunk(P, geo_lanes(Cs, V));
     MPN_CHECK_ARG(chunks == (int)((P + chunk - 1) / chunk));
     dim3 grid((unsigned)chunks, (unsigned)geo_yblocks(Cs, V));
-    if (dtype == MPN_F32)
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, (const float*)z,
-                           (const float*)y, mean, invstd, mask_scale, mask_shift, partial, (long)P, C, Cs, relu, chunk);
-    else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz, (const bf16_t*)z,
-                           (const bf16_t*)y, mean, invstd, mask_scale, mask_shift, partial, (long)P, C, Cs, relu, chunk);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dz, (const T*)z,
+                           (const T*)y, mean, invstd, mask_scale, mask_shift, partial, (long)P, C, Cs, relu, chunk));
     return mpn_launch_status();
 }
 
@@ -352,11 +344,7 @@ extern "C" int mpn_bn_bwd_apply(const void* dz, const void* z, const void* y, co
     MPN_CHECK_ARG(geo_ok(Cs, V) && C % 4 == 0);
     const int lanes = geo_lanes(Cs, V), iters = pick_iters(P, lanes);
     dim3 grid((unsigned)((P + (long)lanes * iters - 1) / ((long)lanes * iters)), (unsigned)geo_yblocks(Cs, V));
-    if (dtype == MPN_F32)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz, (const float*)z,
-                           (const float*)y, k1, k2, k3, mask_scale, mask_shift, (float*)dy, (float*)dres, dres_accumulate, (long)P, C, Cs, relu, iters);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz, (const bf16_t*)z,
-                           (const bf16_t*)y, k1, k2, k3, mask_scale, mask_shift, (bf16_t*)dy, (bf16_t*)dres, dres_accumulate, (long)P, C, Cs, relu, iters);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dz, (const T*)z,
+                           (const T*)y, k1, k2, k3, mask_scale, mask_shift, (T*)dy, (T*)dres, dres_accumulate, (long)P, C, Cs, relu, iters));
     return mpn_launch_status();
 }

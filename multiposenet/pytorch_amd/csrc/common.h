@@ -5,6 +5,7 @@
 #include "../../../include/mpn.h"
 
 typedef unsigned short bf16_t;   // raw bfloat16 storage
+typedef _Float16 f16_t;          // IEEE half (dtype code MPN_F16: the inference arithmetic of BASELINE config 5)
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -34,7 +35,14 @@ template <> struct Elem<bf16_t> {
     __device__ static __forceinline__ float round(float v) { return bf2f(f2bf(v)); }
 };
 
-// 8-element (bf16) / 4-element (f32) 16-byte vectors viewed as floats
+template <> struct Elem<f16_t> {
+    static constexpr int kDtype = MPN_F16;
+    __device__ static __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+    __device__ static __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }      // v_cvt_f16_f32: round to nearest even
+    __device__ static __forceinline__ float round(float v) { return (float)(f16_t)v; }
+};
+
+// 8-element (bf16 / f16) / 4-element (f32) 16-byte vectors viewed as floats
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
     static constexpr int N = 4;
@@ -67,6 +75,24 @@ template <> struct Vec16<bf16_t> {
     }
 };
 
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(8))) float f32x8_t;
+template <> struct Vec16<f16_t> {
+    static constexpr int N = 8;
+    float v[8];
+    __device__ __forceinline__ void load(const f16_t* p) {
+        const f16x8_t t = *reinterpret_cast<const f16x8_t*>(p);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (float)t[k];
+    }
+    __device__ __forceinline__ void store(f16_t* p) const {
+        f16x8_t t;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = (f16_t)v[k];
+        *reinterpret_cast<f16x8_t*>(p) = t;
+    }
+};
+
 // XCD-aware bijective block remap (8 XCDs; block b is observed to run on XCD b % 8): blocks that
 // land on one XCD get a contiguous range of logical tile ids, so neighbouring tiles share an L2.
 __device__ __forceinline__ int xcd_remap(int b, int n) {
@@ -82,3 +108,13 @@ static inline int mpn_launch_status() {
 }
 
 #define MPN_CHECK_ARG(cond) do { if (!(cond)) return MPN_E_BADARG; } while (0)
+
+static inline bool mpn_dtype_ok(int dtype) { return dtype == MPN_F32 || dtype == MPN_BF16 || dtype == MPN_F16; }
+
+// run `...` with T bound to the element type of dtype code `dtype` (callers validate the code first)
+#define MPN_DISPATCH_T(dtype, ...)                                              \
+    do {                                                                        \
+        if ((dtype) == MPN_F32) { using T = float; __VA_ARGS__; }               \
+        else if ((dtype) == MPN_BF16) { using T = bf16_t; __VA_ARGS__; }        \
+        else { using T = f16_t; __VA_ARGS__; }                                  \
+    } while (0)

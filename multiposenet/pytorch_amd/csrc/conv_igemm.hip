@@ -35,6 +35,11 @@ template <> struct Mma<bf16_t> {
                                                       __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
     }
 };
+template <> struct Mma<f16_t> {
+    __device__ static __forceinline__ void run(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+    }
+};
 template <> struct Mma<float> {
     __device__ static __forceinline__ void run(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
         const f32x4_t fa = __builtin_bit_cast(f32x4_t, a);
@@ -70,6 +75,20 @@ template <> struct OutVec4<bf16_t> {
         *reinterpret_cast<uint2*>(p) = t;
     }
     __device__ static __forceinline__ float round(float v) { return bf2f(f2bf(v)); }
+};
+
+template <> struct OutVec4<f16_t> {
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+    __device__ static __forceinline__ void load(const f16_t* p, float v[4]) {
+        const f16x4_t t = *reinterpret_cast<const f16x4_t*>(p);
+        v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+    }
+    __device__ static __forceinline__ void store(f16_t* p, const float v[4]) {
+        f16x4_t t;
+        t[0] = (f16_t)v[0]; t[1] = (f16_t)v[1]; t[2] = (f16_t)v[2]; t[3] = (f16_t)v[3];
+        *reinterpret_cast<f16x4_t*>(p) = t;
+    }
+    __device__ static __forceinline__ float round(float v) { return (float)(f16_t)v; }
 };
 
 template <typename T, int TC, int TP>
@@ -497,7 +516,7 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     const MpnConvParams& p = *pp;
     MPN_CHECK_ARG(p.x && p.w && p.y);
     MPN_CHECK_ARG(p.B > 0 && p.Ho > 0 && p.Wo > 0 && p.H > 0 && p.W > 0);
-    MPN_CHECK_ARG(p.dtype == MPN_F32 || p.dtype == MPN_BF16);
+    MPN_CHECK_ARG(mpn_dtype_ok(p.dtype));
     const int kc = p.dtype == MPN_F32 ? 16 : 32;
     MPN_CHECK_ARG(p.Cin > 0 && p.Cin % kc == 0);
     MPN_CHECK_ARG(p.Cout > 0 && p.Cout_store >= p.Cout && p.Cout_store % 4 == 0);
@@ -514,5 +533,6 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     }          // activation is applied before the residual stage
     hipStream_t st = (hipStream_t)stream;
     if (p.dtype == MPN_F32) return launch_conv<float, false>(p, st);       // OT == T == float
+    if (p.dtype == MPN_F16) return p.out_f32 ? launch_conv<f16_t, true>(p, st) : launch_conv<f16_t, false>(p, st);
     return p.out_f32 ? launch_conv<bf16_t, true>(p, st) : launch_conv<bf16_t, false>(p, st);
 }

@@ -23,6 +23,19 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
+// 16x16x32 MFMA on 8 packed 16-bit values per lane, by element type
+template <typename T> __device__ __forceinline__ f32x4_t mma16(const u32x4_t& a, const u32x4_t& b, const f32x4_t& acc);
+template <> __device__ __forceinline__ f32x4_t mma16<bf16_t>(const u32x4_t& a, const u32x4_t& b, const f32x4_t& acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_t mma16<f16_t>(const u32x4_t& a, const u32x4_t& b, const f32x4_t& acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_t mma16<float>(const u32x4_t&, const u32x4_t&, const f32x4_t& acc) { return acc; }   // never taken
+template <typename T> struct Ones16;
+template <> struct Ones16<bf16_t> { static constexpr unsigned kPair = 0x3F803F80u; };
+template <> struct Ones16<f16_t> { static constexpr unsigned kPair = 0x3C003C00u; };
+
 struct PixState {      // incremental (b, ho, wo) walker over the dense output-pixel index
     int b, ho, wo;
     __device__ __forceinline__ void init(long pix, int Ho, int Wo) {      // pix < 2^31 (checked by the launcher)
@@ -215,8 +228,7 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(const MpnWgradParams
             for (int i = 0; i < C::MM; ++i)
 #pragma unroll
                 for (int j = 0; j < C::MN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[i]),
-                                                                        __builtin_bit_cast(bf16x8_t, fb[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = mma16<T>(fa[i], fb[j], acc[i][j]);
         } else {
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) {
@@ -324,8 +336,8 @@ template <int ROWB> __device__ __forceinline__ int dma_swz(int k) {
     return ROWB >= 256 ? 2 * ((k & 3) | (((k >> 3) & 1) << 2)) : 2 * (((k >> 1) & 1) | (((k >> 3) & 1) << 1));
 }
 
-template <int TM, int TN>
-__global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_kernel(const MpnWgradParams p, long chunk_pixels) {
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& p, long chunk_pixels) {
     constexpr int KP = 32, NST = 3;
     constexpr int ROWA = TM * 2, ROWB = TN * 2;              // bytes per pixel row of each tile
     constexpr int A_BYTES = KP * ROWA, B_BYTES = KP * ROWB;
@@ -411,14 +423,14 @@ __global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_kernel(c
         a_row[h] = k * ROWA; a_swz[h] = dma_swz<ROWA>(k);
         b_row[h] = k * ROWB; b_swz[h] = dma_swz<ROWB>(k);
     }
-    auto frag = [&](const unsigned char* tile, const int (&row)[2], const int (&swz)[2], int c0) -> bf16x8_t {
+    auto frag = [&](const unsigned char* tile, const int (&row)[2], const int (&swz)[2], int c0) -> u32x4_t {
         const int lc = (c0 >> 3) + piece_chunk;          // c0: first channel of the 16-wide block (multiple of 16)
         s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) s16x4_t*)(tile + row[0] + ((lc ^ swz[0]) * 16) + piece_half));
         s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) s16x4_t*)(tile + row[1] + ((lc ^ swz[1]) * 16) + piece_half));
         struct { s16x4_t a, b; } pr = {lo, hi};
-        return __builtin_bit_cast(bf16x8_t, pr);
+        return __builtin_bit_cast(u32x4_t, pr);
     };
     // bias gradient = column sums of dY: the workgroups of the first cin tile / first tap multiply the dY fragments
     // they hold anyway by a vector of ones (one extra MFMA per fragment in two of the four waves)
@@ -426,11 +438,11 @@ __global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_kernel(c
     f32x4_t accb[MN];
 #pragma unroll
     for (int j = 0; j < MN; ++j) accb[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const bf16x8_t ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+    const u32x4_t ones = {Ones16<T>::kPair, Ones16<T>::kPair, Ones16<T>::kPair, Ones16<T>::kPair};
     auto compute = [&](unsigned stage) {
         const unsigned char* la = lds + stage * STAGE_BYTES;
         const unsigned char* lb = la + A_BYTES;
-        bf16x8_t fa[MM], fb[MN];
+        u32x4_t fa[MM], fb[MN];
 #pragma unroll
         for (int i = 0; i < MM; ++i) fa[i] = frag(la, a_row, a_swz, wm * (TM / 2) + i * 16);
 #pragma unroll
@@ -439,10 +451,10 @@ __global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_kernel(c
         for (int i = 0; i < MM; ++i)
 #pragma unroll
             for (int j = 0; j < MN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = mma16<T>(fa[i], fb[j], acc[i][j]);
         if (do_bias) {
 #pragma unroll
-            for (int j = 0; j < MN; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fb[j], accb[j], 0, 0, 0);
+            for (int j = 0; j < MN; ++j) accb[j] = mma16<T>(ones, fb[j], accb[j]);
         }
     };
 
@@ -491,6 +503,15 @@ __global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_kernel(c
             *reinterpret_cast<float4*>(q) = v;
         }
     }
+}
+
+template <int TM, int TN>
+__global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_kernel(const MpnWgradParams p, long chunk_pixels) {
+    conv_wgrad_dma_body<bf16_t, TM, TN>(p, chunk_pixels);
+}
+template <int TM, int TN>
+__global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_f16_kernel(const MpnWgradParams p, long chunk_pixels) {
+    conv_wgrad_dma_body<f16_t, TM, TN>(p, chunk_pixels);
 }
 
 // dst[i] (+)= sum_c ws[c][i], chunks added in index order (deterministic).  (A variant that split the chunks over four
@@ -553,7 +574,7 @@ inline bool wgrad_uses_dma(const MpnWgradParams& p) {
     static const bool use_dma = !(getenv("MPN_WGRAD_NO_DMA") && atoi(getenv("MPN_WGRAD_NO_DMA")));
     const long P = (long)p.B * p.Ho * p.Wo;
     const bool small = (long)p.B * p.x_sB * 2 < 0x7fffffffL && P * p.dy_sP * 2 < 0x7fffffffL;
-    return p.dtype == MPN_BF16 && use_dma && small && p.Cin % 8 == 0;
+    return (p.dtype == MPN_BF16 || p.dtype == MPN_F16) && use_dma && small && p.Cin % 8 == 0;
 }
 
 constexpr long kWgradTarget = 512;       // workgroups per launch (~2 per CU): long slices, little partial-sum traffic
@@ -590,11 +611,15 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st, bool reduce = true) {
     int rc;
     const dim3 g((unsigned)grid), blk(256);
     if (sizeof(T) == 2 && wgrad_uses_dma(p)) {
-        if (tm == 256) hipLaunchKernelGGL((conv_wgrad_dma_kernel<256, 128>), g, blk, 0, st, p, chunk_pixels);
-        else if (tm == 128 && tn == 128) hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 128>), g, blk, 0, st, p, chunk_pixels);
-        else if (tm == 128) hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 64>), g, blk, 0, st, p, chunk_pixels);
-        else if (tn == 128) hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 128>), g, blk, 0, st, p, chunk_pixels);
-        else hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 64>), g, blk, 0, st, p, chunk_pixels);
+#define MPN_WGRAD_DMA_LAUNCH(KERNEL)                                                                                     \
+        if (tm == 256) hipLaunchKernelGGL((KERNEL<256, 128>), g, blk, 0, st, p, chunk_pixels);                           \
+        else if (tm == 128 && tn == 128) hipLaunchKernelGGL((KERNEL<128, 128>), g, blk, 0, st, p, chunk_pixels);         \
+        else if (tm == 128) hipLaunchKernelGGL((KERNEL<128, 64>), g, blk, 0, st, p, chunk_pixels);                       \
+        else if (tn == 128) hipLaunchKernelGGL((KERNEL<64, 128>), g, blk, 0, st, p, chunk_pixels);                       \
+        else hipLaunchKernelGGL((KERNEL<64, 64>), g, blk, 0, st, p, chunk_pixels)
+        if (p.dtype == MPN_F16) { MPN_WGRAD_DMA_LAUNCH(conv_wgrad_dma_f16_kernel); }
+        else { MPN_WGRAD_DMA_LAUNCH(conv_wgrad_dma_kernel); }
+#undef MPN_WGRAD_DMA_LAUNCH
         rc = mpn_launch_status();
     } else if (tm == 128) rc = launch_wgrad_n<T, 128>(p, tn, grid, chunk_pixels, st);
     else if (tm == 64) rc = launch_wgrad_n<T, 64>(p, tn, grid, chunk_pixels, st);
@@ -634,13 +659,14 @@ extern "C" int mpn_conv_wgrad(const MpnWgradParams* pp, void* stream) {
     if (!pp) return MPN_E_BADARG;
     const MpnWgradParams& p = *pp;
     MPN_CHECK_ARG(p.x && p.dy && p.dw);
-    MPN_CHECK_ARG(p.dtype == MPN_F32 || p.dtype == MPN_BF16);
+    MPN_CHECK_ARG(mpn_dtype_ok(p.dtype));
     MPN_CHECK_ARG(p.B > 0 && p.Ho > 0 && p.Wo > 0 && p.Cin > 0 && p.Cout > 0);
     MPN_CHECK_ARG(p.Cin % 8 == 0);
     MPN_CHECK_ARG(p.chunks >= 1 && (p.chunks == 1 || p.ws));
     MPN_CHECK_ARG(!p.db || (wgrad_uses_dma(p) && (p.chunks == 1 || p.db_ws)));
     hipStream_t st = (hipStream_t)stream;
     if (p.dtype == MPN_F32) return launch_wgrad<float>(p, st);
+    if (p.dtype == MPN_F16) return launch_wgrad<f16_t>(p, st);
     return launch_wgrad<bf16_t>(p, st);
 }
 
@@ -648,10 +674,11 @@ extern "C" int mpn_conv_wgrad_partials(const MpnWgradParams* pp, void* stream) {
     if (!pp) return MPN_E_BADARG;
     const MpnWgradParams& p = *pp;
     MPN_CHECK_ARG(p.x && p.dy && p.dw && p.ws && p.chunks > 1);
-    MPN_CHECK_ARG(p.dtype == MPN_F32 || p.dtype == MPN_BF16);
+    MPN_CHECK_ARG(mpn_dtype_ok(p.dtype));
     MPN_CHECK_ARG(p.B > 0 && p.Ho > 0 && p.Wo > 0 && p.Cin > 0 && p.Cout > 0 && p.Cin % 8 == 0);
     hipStream_t st = (hipStream_t)stream;
     if (p.dtype == MPN_F32) return launch_wgrad<float>(p, st, false);
+    if (p.dtype == MPN_F16) return launch_wgrad<f16_t>(p, st, false);
     return launch_wgrad<bf16_t>(p, st, false);
 }
 

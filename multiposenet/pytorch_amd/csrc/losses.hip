@@ -274,11 +274,11 @@ __global__ void sigmoid_fwd_kernel(const float* __restrict__ x, float* __restric
 }
 
 // ------------------------------------------------------------------------------- PRN pieces
-__global__ void add_softmax_rows_kernel(const float* __restrict__ a, const float* __restrict__ res, float* __restrict__ out, int cols, int relu) {
+__global__ void add_softmax_rows_kernel(const float* __restrict__ a, long a_stride, const float* __restrict__ res, float* __restrict__ out, int cols, int relu) {
     __shared__ float sh[4];
     __shared__ float bc;
     const long row = blockIdx.x;
-    const float* pa = a + row * cols; const float* pr = res + row * cols; float* po = out + row * cols;
+    const float* pa = a + row * a_stride; const float* pr = res + row * cols; float* po = out + row * cols;
     float mx = -INFINITY;
     const float lo = relu ? 0.f : -INFINITY;      // F.relu(dens2(.)) is folded in (posenet.py:343)
     for (int i = threadIdx.x; i < cols; i += 256) mx = fmaxf(mx, fmaxf(pa[i], lo) + pr[i]);
@@ -301,7 +301,7 @@ __global__ void add_softmax_rows_kernel(const float* __restrict__ a, const float
 }
 
 // dlogit[r][i] = p * (dp - sum_j p_j dp_j)  (softmax backward, one block per row)
-__global__ void softmax_rows_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp, const float* __restrict__ pre, float* __restrict__ dl, int cols) {
+__global__ void softmax_rows_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp, const float* __restrict__ pre, long pre_stride, float* __restrict__ dl, int cols) {
     __shared__ float sh[4];
     __shared__ float bc;
     const long row = blockIdx.x;
@@ -316,7 +316,7 @@ __global__ void softmax_rows_bwd_kernel(const float* __restrict__ p, const float
     const float dot = bc;
     for (int i = threadIdx.x; i < cols; i += 256) {
         const float g = pp[i] * (pd[i] - dot);
-        po[i] = (pre == nullptr || pre[row * cols + i] > 0.f) ? g : 0.f;      // relu mask of the pre-activation
+        po[i] = (pre == nullptr || pre[row * pre_stride + i] > 0.f) ? g : 0.f;      // relu mask of the pre-activation
     }
 }
 
@@ -433,15 +433,15 @@ extern "C" int mpn_sigmoid_forward(const float* x, float* y, int64_t n, void* st
     return mpn_launch_status();
 }
 
-extern "C" int mpn_add_softmax_rows(const float* a, const float* res, float* out, int rows, int cols, int relu, void* stream) {
-    MPN_CHECK_ARG(a && res && out && rows > 0 && cols > 0);
-    hipLaunchKernelGGL(add_softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, a, res, out, cols, relu);
+extern "C" int mpn_add_softmax_rows(const float* a, int64_t a_stride, const float* res, float* out, int rows, int cols, int relu, void* stream) {
+    MPN_CHECK_ARG(a && res && out && rows > 0 && cols > 0 && a_stride >= cols);
+    hipLaunchKernelGGL(add_softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, a, (long)a_stride, res, out, cols, relu);
     return mpn_launch_status();
 }
 
-extern "C" int mpn_softmax_rows_backward(const float* p, const float* dp, const float* pre_relu, float* dlogit, int rows, int cols, void* stream) {
-    MPN_CHECK_ARG(p && dp && dlogit && rows > 0 && cols > 0);
-    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, p, dp, pre_relu, dlogit, cols);
+extern "C" int mpn_softmax_rows_backward(const float* p, const float* dp, const float* pre_relu, int64_t pre_stride, float* dlogit, int rows, int cols, void* stream) {
+    MPN_CHECK_ARG(p && dp && dlogit && rows > 0 && cols > 0 && (!pre_relu || pre_stride >= cols));
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, p, dp, pre_relu, (long)pre_stride, dlogit, cols);
     return mpn_launch_status();
 }
 
@@ -454,8 +454,7 @@ extern "C" int mpn_bce_mean_backward(const float* p, const float* label, float* 
 extern "C" int mpn_dropout(const void* x, void* y, int64_t n, uint64_t seed, float p, int dtype, void* stream) {
     MPN_CHECK_ARG(x && y && n > 0 && p >= 0.f && p < 1.f);
     const float scale = 1.0f / (1.0f - p);
-    if (dtype == MPN_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, (long)n, (unsigned long long)seed, p, scale);
-    else hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (long)n, (unsigned long long)seed, p, scale);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, (long)n, (unsigned long long)seed, p, scale));
     return mpn_launch_status();
 }
 

@@ -14,6 +14,7 @@
 //   2. mask: one wave per 64x64 tile of the UPPER triangle; lane t owns row box t, column boxes are
 //      broadcast lane-to-lane (v_readlane) — no LDS; the reference also fills the lower triangle,
 //      which its scan never reads.
+//      Tile pairs are enumerated triangularly, so no workgroup is launched for the lower half.
 //   3. scan ON DEVICE (the reference copies the whole N*N/64 mask to the host): one workgroup walks
 //      the 64-box blocks; the diagonal word resolves intra-block suppression with scalar bit ops,
 //      kept rows are OR-ed into the removal vector in parallel.  Only `keep`/`num` leave the GPU.
@@ -50,11 +51,17 @@ __global__ void clip_boxes_kernel(float* __restrict__ boxes, long n, float img_w
     *reinterpret_cast<float4*>(boxes + i * 4) = b;
 }
 
-// single workgroup (1024 threads), order-preserving compaction of image-0 candidates
-__global__ void score_filter_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, int A, float thresh,
-                                    float* __restrict__ dets, int* __restrict__ src_idx, int* __restrict__ count) {
+// one workgroup (1024 threads) per image, order-preserving compaction of the candidates with score > thresh
+__global__ void __launch_bounds__(1024) score_filter_kernel(const float* __restrict__ boxes_all, const float* __restrict__ scores_all, int A,
+                                                            float thresh, float* __restrict__ dets_all, int* __restrict__ src_all,
+                                                            int* __restrict__ count) {
     __shared__ int wave_cnt[16];
     __shared__ int base_s;
+    const int img = blockIdx.x;
+    const float* __restrict__ boxes = boxes_all + (long)img * A * 4;
+    const float* __restrict__ scores = scores_all + (long)img * A;
+    float* __restrict__ dets = dets_all + (long)img * A * 5;
+    int* __restrict__ src_idx = src_all ? src_all + (long)img * A : nullptr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) base_s = 0;
     __syncthreads();
@@ -71,18 +78,35 @@ __global__ void score_filter_kernel(const float* __restrict__ boxes, const float
             const float4 b = *reinterpret_cast<const float4*>(boxes + (long)a * 4);
             float* o = dets + (long)pos * 5;
             o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w; o[4] = scores[a];
-            src_idx[pos] = a;
+            if (src_idx) src_idx[pos] = a;
         }
         __syncthreads();
         if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wave_cnt[w]; base_s += t; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) count[0] = base_s;
+    if (threadIdx.x == 0) count[img] = base_s;
 }
 
 // ---------------------------------------------------------------------------------- NMS
-__global__ void nms_rank_kernel(const float* __restrict__ dets, int n, float* __restrict__ sorted, int* __restrict__ order) {
+// Every kernel below serves one image per blockIdx.z (or .x for the scan): image b has n = counts[b] candidates (counts ==
+// NULL: n_host for the single image), its rows start at dets + b*dets_stride, its scratch at b*ws_stride bytes.
+struct NmsBatch {
+    const float* dets; long dets_stride;         // candidate rows [n][5] per image (floats between images)
+    const int* counts; int n_host;
+    char* ws; long ws_stride;                    // per image: sorted [nmax*5 f32] | order [nmax i32] | remv [cb u64] | mask [nmax*cb u64]
+    long off_order, off_remv, off_mask;
+    int cb;                                      // mask words per row = ceil(nmax / 64)
+};
+__device__ __forceinline__ int nb_count(const NmsBatch& q, int b) { return q.counts ? q.counts[b] : q.n_host; }
+
+__global__ void nms_rank_kernel(const NmsBatch q) {
     __shared__ float ssc[1024];
+    const int b = blockIdx.z;
+    const int n = nb_count(q, b);
+    if ((int)(blockIdx.x * blockDim.x) >= n) return;
+    const float* __restrict__ dets = q.dets + (long)b * q.dets_stride;
+    float* __restrict__ sorted = reinterpret_cast<float*>(q.ws + (long)b * q.ws_stride);
+    int* __restrict__ order = reinterpret_cast<int*>(q.ws + (long)b * q.ws_stride + q.off_order);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const float si = (i < n) ? dets[(long)i * 5 + 4] : 0.f;
     int rank = 0;
@@ -116,16 +140,26 @@ __device__ __forceinline__ float dev_iou(const float a0, const float a1, const f
     return interS / (Sa + Sb - interS);
 }
 
-// grid (col_blocks, col_blocks), block 64 (one wave); only col >= row tiles do work
-__global__ void __launch_bounds__(64) nms_mask_kernel(const float* __restrict__ sorted, int n, float thresh, int mode,
-                                                      unsigned long long* __restrict__ mask, int cb) {
-    const int row_blk = blockIdx.y, col_blk = blockIdx.x;
-    if (col_blk < row_blk) return;
+// One wave per 64x64 tile of the UPPER triangle (tile pairs are enumerated so that no workgroup is launched for the
+// lower half): blockIdx.x = row_blk * cb - row_blk*(row_blk-1)/2 + (col_blk - row_blk).
+__global__ void __launch_bounds__(64) nms_mask_kernel(const NmsBatch q, float thresh, int mode) {
+    const int b = blockIdx.z;
+    const int n = nb_count(q, b);
+    const int cbn = (n + 63) / 64;               // live tiles per side for this image
+    // invert the triangular index with the launch-wide cb
+    const int cb = q.cb;
+    int row_blk = (int)((2.0 * cb + 1.0 - sqrt((2.0 * cb + 1.0) * (2.0 * cb + 1.0) - 8.0 * (double)blockIdx.x)) * 0.5);
+    while (row_blk > 0 && (long)row_blk * cb - (long)row_blk * (row_blk - 1) / 2 > (long)blockIdx.x) --row_blk;
+    while ((long)(row_blk + 1) * cb - (long)(row_blk + 1) * row_blk / 2 <= (long)blockIdx.x) ++row_blk;
+    const int col_blk = row_blk + (int)((long)blockIdx.x - ((long)row_blk * cb - (long)row_blk * (row_blk - 1) / 2));
+    if (row_blk >= cbn || col_blk >= cbn) return;
+    const float* __restrict__ sorted = reinterpret_cast<const float*>(q.ws + (long)b * q.ws_stride);
+    unsigned long long* __restrict__ mask = reinterpret_cast<unsigned long long*>(q.ws + (long)b * q.ws_stride + q.off_mask);
     const int t = threadIdx.x;
     const int row = row_blk * 64 + t, col = col_blk * 64 + t;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
-    if (col < n) { const float* q = sorted + (long)col * 5; c0 = q[0]; c1 = q[1]; c2 = q[2]; c3 = q[3]; }
-    if (row < n) { const float* q = sorted + (long)row * 5; r0 = q[0]; r1 = q[1]; r2 = q[2]; r3 = q[3]; }
+    if (col < n) { const float* p = sorted + (long)col * 5; c0 = p[0]; c1 = p[1]; c2 = p[2]; c3 = p[3]; }
+    if (row < n) { const float* p = sorted + (long)row * 5; r0 = p[0]; r1 = p[1]; r2 = p[2]; r3 = p[3]; }
     const int col_size = (n - col_blk * 64) < 64 ? (n - col_blk * 64) : 64;
     unsigned long long bits = 0ull;
     const int start = (row_blk == col_blk) ? t + 1 : 0;       // nms_kernel.cu:58-61
@@ -138,17 +172,24 @@ __global__ void __launch_bounds__(64) nms_mask_kernel(const float* __restrict__ 
     if (row < n) mask[(long)row * cb + col_blk] = bits;
 }
 
-// one workgroup of 1024 threads
-__global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ order,
-                                                        int n, int cb, unsigned long long* __restrict__ remv,
-                                                        int64_t* __restrict__ keep_out, int64_t* __restrict__ num_out) {
+// one workgroup of 1024 threads per image
+__global__ void __launch_bounds__(1024) nms_scan_kernel(const NmsBatch q, int64_t* __restrict__ keep_all, long keep_stride,
+                                                        int64_t* __restrict__ num_out) {
     __shared__ unsigned long long keep_word;
     __shared__ int base_cnt;
+    const int b = blockIdx.x;
+    const int n = nb_count(q, b);
+    const int cb = q.cb;
+    const int cbn = (n + 63) / 64;
+    const int* __restrict__ order = reinterpret_cast<const int*>(q.ws + (long)b * q.ws_stride + q.off_order);
+    unsigned long long* __restrict__ remv = reinterpret_cast<unsigned long long*>(q.ws + (long)b * q.ws_stride + q.off_remv);
+    const unsigned long long* __restrict__ mask = reinterpret_cast<const unsigned long long*>(q.ws + (long)b * q.ws_stride + q.off_mask);
+    int64_t* __restrict__ keep_out = keep_all + (long)b * keep_stride;
     const int tid = threadIdx.x;
-    for (int j = tid; j < cb; j += 1024) remv[j] = 0ull;
+    for (int j = tid; j < cbn; j += 1024) remv[j] = 0ull;
     if (tid == 0) base_cnt = 0;
     __syncthreads();
-    for (int bi = 0; bi < cb; ++bi) {
+    for (int bi = 0; bi < cbn; ++bi) {
         if (tid < 64) {
             const int row = bi * 64 + tid;
             const unsigned long long diag = (row < n) ? mask[(long)row * cb + bi] : 0ull;
@@ -168,7 +209,7 @@ __global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long
         __syncthreads();
         const unsigned long long kept = keep_word;
         if (kept) {
-            for (int j = bi + 1 + tid; j < cb; j += 1024) {
+            for (int j = bi + 1 + tid; j < cbn; j += 1024) {
                 unsigned long long acc = remv[j];
                 unsigned long long k = kept;
                 while (k) {
@@ -183,17 +224,22 @@ __global__ void __launch_bounds__(1024) nms_scan_kernel(const unsigned long long
         if (tid == 0) base_cnt += __popcll(kept);
         __syncthreads();
     }
-    if (tid == 0) num_out[0] = (int64_t)base_cnt;
+    if (tid == 0) num_out[b] = (int64_t)base_cnt;
 }
 
-// rows of dets[n,5] selected by keep[k] -> boxes[k,4], scores[k]  (posenet.py:283-285 gathers)
-__global__ void gather_dets_kernel(const float* __restrict__ dets, const int64_t* __restrict__ keep, int k,
-                                   float* __restrict__ boxes, float* __restrict__ scores) {
+// rows of dets[n,5] selected by keep[k] -> boxes[k,4], scores[k]  (posenet.py:283-285 gathers); image = blockIdx.y,
+// k = num[image] when num != NULL
+__global__ void gather_dets_kernel(const float* __restrict__ dets_all, long dets_stride, const int64_t* __restrict__ keep_all, long keep_stride,
+                                   const int64_t* __restrict__ num, int k_host, float* __restrict__ boxes_all, float* __restrict__ scores_all,
+                                   long out_stride) {
+    const int b = blockIdx.y;
+    const int k = num ? (int)num[b] : k_host;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= k) return;
-    const float* s = dets + keep[i] * 5;
+    const float* s = dets_all + (long)b * dets_stride + keep_all[(long)b * keep_stride + i] * 5;
+    float* boxes = boxes_all + (long)b * out_stride * 4;
     boxes[i * 4 + 0] = s[0]; boxes[i * 4 + 1] = s[1]; boxes[i * 4 + 2] = s[2]; boxes[i * 4 + 3] = s[3];
-    scores[i] = s[4];
+    scores_all[(long)b * out_stride + i] = s[4];
 }
 
 inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
@@ -222,16 +268,58 @@ extern "C" int mpn_score_filter(const float* boxes, const float* scores, int A, 
     return mpn_launch_status();
 }
 
-extern "C" int mpn_gather_dets(const float* dets, const int64_t* keep, int k, float* boxes, float* scores, void* stream) {
-    MPN_CHECK_ARG(dets && keep && boxes && scores && k > 0);
-    hipLaunchKernelGGL(gather_dets_kernel, dim3((k + 255) / 256), dim3(256), 0, (hipStream_t)stream, dets, keep, k, boxes, scores);
+extern "C" int mpn_score_filter_batched(const float* boxes, const float* scores, int B, int A, float thresh, float* dets,
+                                        int32_t* src_idx, int32_t* counts, void* stream) {
+    MPN_CHECK_ARG(boxes && scores && dets && counts && B > 0 && A > 0);
+    hipLaunchKernelGGL(score_filter_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, boxes, scores, A, thresh, dets, src_idx, counts);
     return mpn_launch_status();
 }
 
+extern "C" int mpn_gather_dets(const float* dets, const int64_t* keep, int k, float* boxes, float* scores, void* stream) {
+    MPN_CHECK_ARG(dets && keep && boxes && scores && k > 0);
+    hipLaunchKernelGGL(gather_dets_kernel, dim3((k + 255) / 256, 1), dim3(256), 0, (hipStream_t)stream, dets, 0L, keep, 0L,
+                       (const int64_t*)nullptr, k, boxes, scores, 0L);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_gather_dets_batched(const float* dets, int64_t dets_stride, const int64_t* keep, int64_t keep_stride, const int64_t* num,
+                                       int B, int kmax, float* boxes, float* scores, int64_t out_stride, void* stream) {
+    MPN_CHECK_ARG(dets && keep && num && boxes && scores && B > 0 && kmax > 0 && out_stride >= kmax);
+    hipLaunchKernelGGL(gather_dets_kernel, dim3((kmax + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, dets, (long)dets_stride, keep,
+                       (long)keep_stride, num, 0, boxes, scores, (long)out_stride);
+    return mpn_launch_status();
+}
+
+namespace {
+struct NmsLayout { long off_order, off_remv, off_mask, total; int cb; };
+inline NmsLayout nms_layout(long nmax) {
+    NmsLayout l;
+    l.cb = (int)((nmax + 63) / 64);
+    l.off_order = align_up(nmax * 5 * 4, 256);
+    l.off_remv = l.off_order + align_up(nmax * 4, 256);
+    l.off_mask = l.off_remv + align_up((long)l.cb * 8, 256);
+    l.total = l.off_mask + align_up(nmax * (long)l.cb * 8, 256);
+    return l;
+}
+inline int launch_nms(const float* dets, long dets_stride, const int* counts, int n_host, int B, long nmax, float thresh, int mode,
+                      int64_t* keep_out, long keep_stride, int64_t* num_out, void* workspace, hipStream_t st) {
+    const NmsLayout l = nms_layout(nmax);
+    NmsBatch q;
+    q.dets = dets; q.dets_stride = dets_stride; q.counts = counts; q.n_host = n_host;
+    q.ws = (char*)workspace; q.ws_stride = l.total;
+    q.off_order = l.off_order; q.off_remv = l.off_remv; q.off_mask = l.off_mask; q.cb = l.cb;
+    const long tri = (long)l.cb * (l.cb + 1) / 2;
+    if (tri > 0x7fffffffL) return MPN_E_UNSUPPORTED;
+    hipLaunchKernelGGL(nms_rank_kernel, dim3((unsigned)((nmax + 255) / 256), 1, B), dim3(256), 0, st, q);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)tri, 1, B), dim3(64), 0, st, q, thresh, mode);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(1024), 0, st, q, keep_out, keep_stride, num_out);
+    return mpn_launch_status();
+}
+}  // namespace
+
 extern "C" int64_t mpn_nms_workspace_bytes(int64_t n) {
     if (n <= 0) return 256;
-    const long cb = (n + 63) / 64;
-    return align_up(n * 5 * 4, 256) + align_up(n * 4, 256) + align_up(cb * 8, 256) + align_up(n * cb * 8, 256);
+    return nms_layout(n).total;
 }
 
 extern "C" int mpn_nms(const float* dets, int64_t n, float thresh, int mode, int64_t* keep_out, int64_t* num_out,
@@ -240,16 +328,18 @@ extern "C" int mpn_nms(const float* dets, int64_t n, float thresh, int mode, int
     hipStream_t st = (hipStream_t)stream;
     if (n <= 0) return (int)hipMemsetAsync(num_out, 0, sizeof(int64_t), st);
     MPN_CHECK_ARG(dets && keep_out && workspace && n < (1 << 30));
-    const int N = (int)n;
-    const int cb = (N + 63) / 64;
-    char* ws = (char*)workspace;
-    float* sorted = (float*)ws;               ws += align_up((long)N * 5 * 4, 256);
-    int* order = (int*)ws;                    ws += align_up((long)N * 4, 256);
-    unsigned long long* remv = (unsigned long long*)ws; ws += align_up((long)cb * 8, 256);
-    unsigned long long* mask = (unsigned long long*)ws;
-    hipLaunchKernelGGL(nms_rank_kernel, dim3((N + 255) / 256), dim3(256), 0, st, dets, N, sorted, order);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb), dim3(64), 0, st, (const float*)sorted, N, thresh, mode, mask, cb);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), 0, st, (const unsigned long long*)mask, (const int*)order, N, cb, remv,
-                       keep_out, num_out);
-    return mpn_launch_status();
+    return launch_nms(dets, 0, nullptr, (int)n, 1, (long)n, thresh, mode, keep_out, 0, num_out, workspace, st);
+}
+
+extern "C" int64_t mpn_nms_batched_workspace_bytes(int B, int64_t nmax) {
+    if (B <= 0 || nmax <= 0) return 256;
+    return (int64_t)B * nms_layout(nmax).total;
+}
+
+extern "C" int mpn_nms_batched(const float* dets, int64_t dets_stride, const int32_t* counts, int B, int64_t nmax, float thresh, int mode,
+                               int64_t* keep_out, int64_t keep_stride, int64_t* num_out, void* workspace, void* stream) {
+    MPN_CHECK_ARG(dets && counts && keep_out && num_out && workspace && B > 0 && (mode == 0 || mode == 1));
+    MPN_CHECK_ARG(nmax > 0 && nmax < (1 << 30) && keep_stride >= nmax && dets_stride >= nmax * 5);
+    return launch_nms(dets, (long)dets_stride, counts, 0, B, (long)nmax, thresh, mode, keep_out, (long)keep_stride, num_out, workspace,
+                      (hipStream_t)stream);
 }

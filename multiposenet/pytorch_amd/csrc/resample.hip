@@ -307,8 +307,7 @@ extern "C" int mpn_maxpool3x3s2_forward(const void* x, void* y, uint8_t* idx, in
     MPN_CHECK_ARG(x && y && B > 0 && Cs % 8 == 0 && Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1);
     const int V = dtype == MPN_F32 ? 4 : 8;
     const long n = (long)B * Ho * Wo * (Cs / V);
-    if (dtype == MPN_F32) hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, idx, B, H, W, Cs, Ho, Wo);
-    else hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, idx, B, H, W, Cs, Ho, Wo);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, idx, B, H, W, Cs, Ho, Wo));
     return mpn_launch_status();
 }
 
@@ -317,8 +316,7 @@ extern "C" int mpn_maxpool3x3s2_backward(const void* dy, const uint8_t* idx, voi
     MPN_CHECK_ARG(dy && idx && dx && B > 0 && Cs % 8 == 0);
     const int V = dtype == MPN_F32 ? 4 : 8;
     const long n = (long)B * H * W * (Cs / V);
-    if (dtype == MPN_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, idx, (float*)dx, B, H, W, Cs, Ho, Wo);
-    else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, idx, (bf16_t*)dx, B, H, W, Cs, Ho, Wo);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, idx, (T*)dx, B, H, W, Cs, Ho, Wo));
     return mpn_launch_status();
 }
 
@@ -327,8 +325,7 @@ extern "C" int mpn_upsample_nearest_backward(const void* dfine, void* dcoarse, i
     MPN_CHECK_ARG(dfine && dcoarse && B > 0 && Cs % 8 == 0);
     const int V = dtype == MPN_F32 ? 4 : 8;
     const long n = (long)B * Hc * Wc * (Cs / V);
-    if (dtype == MPN_F32) hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const float*)dfine, (long)Cs, 0, (float*)dcoarse, B, Hf, Wf, Hc, Wc, Cs, Cs, accumulate);
-    else hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dfine, (long)Cs, 0, (bf16_t*)dcoarse, B, Hf, Wf, Hc, Wc, Cs, Cs, accumulate);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const T*)dfine, (long)Cs, 0, (T*)dcoarse, B, Hf, Wf, Hc, Wc, Cs, Cs, accumulate));
     return mpn_launch_status();
 }
 
@@ -337,8 +334,7 @@ extern "C" int mpn_upsample_nearest_slice(const void* src, void* dst, int B, int
     MPN_CHECK_ARG(src && dst && B > 0 && Cs_src % 8 == 0 && Cs_dst % 8 == 0 && c_off % 8 == 0);
     const int V = dtype == MPN_F32 ? 4 : 8;
     const long n = (long)B * Ho * Wo * (Cs_src / V);
-    if (dtype == MPN_F32) hipLaunchKernelGGL(upsample_slice_kernel<float>, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const float*)src, (float*)dst, B, Hs, Ws, Cs_src, Ho, Wo, Cs_dst, c_off);
-    else hipLaunchKernelGGL(upsample_slice_kernel<bf16_t>, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, B, Hs, Ws, Cs_src, Ho, Wo, Cs_dst, c_off);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((upsample_slice_kernel<T>), dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const T*)src, (T*)dst, B, Hs, Ws, Cs_src, Ho, Wo, Cs_dst, c_off));
     return mpn_launch_status();
 }
 
@@ -347,8 +343,7 @@ extern "C" int mpn_upsample_nearest_slice_backward(const void* ddst, void* dsrc,
     MPN_CHECK_ARG(ddst && dsrc && B > 0 && Cs_src % 8 == 0 && Cs_dst % 8 == 0 && c_off % 8 == 0);
     const int V = dtype == MPN_F32 ? 4 : 8;
     const long n = (long)B * Hs * Ws * (Cs_src / V);
-    if (dtype == MPN_F32) hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const float*)ddst, (long)Cs_dst, c_off, (float*)dsrc, B, Ho, Wo, Hs, Ws, Cs_src, Cs_src, 0);
-    else hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)ddst, (long)Cs_dst, c_off, (bf16_t*)dsrc, B, Ho, Wo, Hs, Ws, Cs_src, Cs_src, 0);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const T*)ddst, (long)Cs_dst, c_off, (T*)dsrc, B, Ho, Wo, Hs, Ws, Cs_src, Cs_src, 0));
     return mpn_launch_status();
 }
 
@@ -356,8 +351,7 @@ extern "C" int mpn_export_f32(const void* src, int src_dtype, float* dst, int B,
                               int64_t dst_sB, int64_t dst_sP, void* stream) {
     MPN_CHECK_ARG(src && dst && B > 0 && C > 0 && Cs >= C);
     const long n = (long)B * Ho * Wo * C;
-    if (src_dtype == MPN_F32) hipLaunchKernelGGL(export_f32_kernel<float>, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, B, Hs, Ws, Cs, C, Ho, Wo, (long)dst_sB, (long)dst_sP);
-    else hipLaunchKernelGGL(export_f32_kernel<bf16_t>, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, B, Hs, Ws, Cs, C, Ho, Wo, (long)dst_sB, (long)dst_sP);
+    MPN_DISPATCH_T(src_dtype, hipLaunchKernelGGL((export_f32_kernel<T>), dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const T*)src, dst, B, Hs, Ws, Cs, C, Ho, Wo, (long)dst_sB, (long)dst_sP));
     return mpn_launch_status();
 }
 
@@ -365,8 +359,7 @@ extern "C" int mpn_import_grad(const float* ddst, int64_t ddst_sB, int64_t ddst_
                                int Cs, int C, int Ho, int Wo, void* stream) {
     MPN_CHECK_ARG(ddst && dsrc && B > 0 && C > 0 && Cs >= C);
     const long n = (long)B * Hs * Ws * Cs;
-    if (dst_dtype == MPN_F32) hipLaunchKernelGGL(import_grad_kernel<float>, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, ddst, (long)ddst_sB, (long)ddst_sP, (float*)dsrc, B, Hs, Ws, Cs, C, Ho, Wo);
-    else hipLaunchKernelGGL(import_grad_kernel<bf16_t>, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, ddst, (long)ddst_sB, (long)ddst_sP, (bf16_t*)dsrc, B, Hs, Ws, Cs, C, Ho, Wo);
+    MPN_DISPATCH_T(dst_dtype, hipLaunchKernelGGL((import_grad_kernel<T>), dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, ddst, (long)ddst_sB, (long)ddst_sP, (T*)dsrc, B, Hs, Ws, Cs, C, Ho, Wo));
     return mpn_launch_status();
 }
 
@@ -381,16 +374,14 @@ extern "C" int mpn_nchw_to_nhwc_f32(const float* src, int64_t sB, int64_t sC, in
 extern "C" int mpn_det_pack(const void* src, int src_dtype, float* dst, int B, int64_t HW, int Cs, int C, int64_t dst_sB, void* stream) {
     MPN_CHECK_ARG(src && dst && B > 0 && C > 0 && Cs >= C);
     const long n = (long)B * HW * C;
-    if (src_dtype == MPN_F32) hipLaunchKernelGGL(det_pack_kernel<float>, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, B, (long)HW, Cs, C, (long)dst_sB);
-    else hipLaunchKernelGGL(det_pack_kernel<bf16_t>, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, B, (long)HW, Cs, C, (long)dst_sB);
+    MPN_DISPATCH_T(src_dtype, hipLaunchKernelGGL((det_pack_kernel<T>), dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, (const T*)src, dst, B, (long)HW, Cs, C, (long)dst_sB));
     return mpn_launch_status();
 }
 
 extern "C" int mpn_det_unpack(const float* ddst, void* dsrc, int dst_dtype, int B, int64_t HW, int Cs, int C, int64_t dst_sB, void* stream) {
     MPN_CHECK_ARG(ddst && dsrc && B > 0 && C > 0 && Cs >= C);
     const long n = (long)B * HW * Cs;
-    if (dst_dtype == MPN_F32) hipLaunchKernelGGL(det_unpack_kernel<float>, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, ddst, (float*)dsrc, B, (long)HW, Cs, C, (long)dst_sB);
-    else hipLaunchKernelGGL(det_unpack_kernel<bf16_t>, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, ddst, (bf16_t*)dsrc, B, (long)HW, Cs, C, (long)dst_sB);
+    MPN_DISPATCH_T(dst_dtype, hipLaunchKernelGGL((det_unpack_kernel<T>), dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, ddst, (T*)dsrc, B, (long)HW, Cs, C, (long)dst_sB));
     return mpn_launch_status();
 }
 
@@ -398,8 +389,7 @@ extern "C" int mpn_relu_backward(const void* dz, const void* z, void* dx, int64_
     MPN_CHECK_ARG(dz && z && dx && n > 0 && n % 8 == 0);
     const int V = dtype == MPN_F32 ? 4 : 8;
     const long nvec = n / V;
-    if (dtype == MPN_F32) hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(nb(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)dz, (const float*)z, (float*)dx, nvec, accumulate);
-    else hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(nb(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz, (const bf16_t*)z, (bf16_t*)dx, nvec, accumulate);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((relu_bwd_kernel<T>), dim3(nb(nvec)), dim3(256), 0, (hipStream_t)stream, (const T*)dz, (const T*)z, (T*)dx, nvec, accumulate));
     return mpn_launch_status();
 }
 
@@ -407,8 +397,7 @@ extern "C" int mpn_relu_forward(const void* x, void* y, int64_t n, int dtype, vo
     MPN_CHECK_ARG(x && y && n > 0 && n % 8 == 0);
     const int V = dtype == MPN_F32 ? 4 : 8;
     const long nvec = n / V;
-    if (dtype == MPN_F32) hipLaunchKernelGGL(relu_fwd_kernel<float>, dim3(nb(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, nvec);
-    else hipLaunchKernelGGL(relu_fwd_kernel<bf16_t>, dim3(nb(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, nvec);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((relu_fwd_kernel<T>), dim3(nb(nvec)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, nvec));
     return mpn_launch_status();
 }
 
@@ -416,15 +405,13 @@ extern "C" int mpn_add_inplace(void* dst, const void* src, int64_t n, int dtype,
     MPN_CHECK_ARG(dst && src && n > 0 && n % 8 == 0);
     const int V = dtype == MPN_F32 ? 4 : 8;
     const long nvec = n / V;
-    if (dtype == MPN_F32) hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(nb(nvec)), dim3(256), 0, (hipStream_t)stream, (float*)dst, (const float*)src, nvec);
-    else hipLaunchKernelGGL(add_inplace_kernel<bf16_t>, dim3(nb(nvec)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dst, (const bf16_t*)src, nvec);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((add_inplace_kernel<T>), dim3(nb(nvec)), dim3(256), 0, (hipStream_t)stream, (T*)dst, (const T*)src, nvec));
     return mpn_launch_status();
 }
 
 extern "C" int mpn_colsum_rows(const void* dy, int dy_dtype, int64_t P, int C, int Cs, float* db, void* stream) {
     MPN_CHECK_ARG(dy && db && P > 0 && C > 0 && Cs >= C);
-    if (dy_dtype == MPN_F32) hipLaunchKernelGGL(colsum_rows_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (long)P, C, Cs, db);
-    else hipLaunchKernelGGL(colsum_rows_kernel<bf16_t>, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (long)P, C, Cs, db);
+    MPN_DISPATCH_T(dy_dtype, hipLaunchKernelGGL((colsum_rows_kernel<T>), dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (long)P, C, Cs, db));
     return mpn_launch_status();
 }
 
@@ -444,7 +431,6 @@ extern "C" int mpn_channel_sum(const void* dy, int dy_dtype, int64_t P, int C, i
     const int chunk = cs_chunk(P, cs_lanes(Cs, V));
     MPN_CHECK_ARG(chunks == (int)((P + chunk - 1) / chunk));
     dim3 grid((unsigned)chunks, (unsigned)(G <= 256 ? 1 : G / 256));
-    if (dy_dtype == MPN_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy, (long)P, C, Cs, partial, chunk);
-    else hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (long)P, C, Cs, partial, chunk);
+    MPN_DISPATCH_T(dy_dtype, hipLaunchKernelGGL((channel_sum_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dy, (long)P, C, Cs, partial, chunk));
     return mpn_launch_status();
 }

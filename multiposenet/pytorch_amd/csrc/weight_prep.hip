@@ -9,6 +9,7 @@
 //   * stem (7x7x3)     : [64][7][32] packing that turns the Cin=3 stem into a Cin=32 "row" conv
 // Adam follows torch.optim.Adam (training/multipose_keypoint_train.py:106-110, trainer.py:259).
 #include "common.h"
+#include "build_id.h"
 
 namespace {
 
@@ -26,6 +27,20 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __re
         *reinterpret_cast<uint4*>(dst + i) = o;
     } else {
         for (long k = i; k < n; ++k) dst[k] = f2bf(src[k]);
+    }
+}
+
+__global__ void cast_f32_f16_kernel(const float* __restrict__ src, f16_t* __restrict__ dst, long n) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i >= n) return;
+    if (i + 7 < n) {
+        Vec16<f16_t> o;
+        const float4 a = *reinterpret_cast<const float4*>(src + i);
+        const float4 b = *reinterpret_cast<const float4*>(src + i + 4);
+        o.v[0] = a.x; o.v[1] = a.y; o.v[2] = a.z; o.v[3] = a.w; o.v[4] = b.x; o.v[5] = b.y; o.v[6] = b.z; o.v[7] = b.w;
+        o.store(dst + i);
+    } else {
+        for (long k = i; k < n; ++k) dst[k] = (f16_t)src[k];
     }
 }
 
@@ -144,6 +159,56 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// Device-resident optimizer state (so that a captured hipGraph replays correct steps): hyper[0..7] =
+// {lr, beta1, beta2, eps, weight_decay, grad_scale, bias_correction1, sqrt(bias_correction2)}, hyper[8] = step (as float
+// bits of an int32).  adam_advance increments the step and refreshes the two bias corrections in double precision,
+// exactly the values torch.optim.Adam computes on the host.
+__global__ void adam_advance_kernel(float* __restrict__ hyper) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int* stepp = reinterpret_cast<int*>(hyper + 8);
+    const int t = *stepp + 1;
+    *stepp = t;
+    const double b1 = (double)hyper[1], b2 = (double)hyper[2];
+    hyper[6] = (float)(1.0 - pow(b1, (double)t));
+    hyper[7] = (float)sqrt(1.0 - pow(b2, (double)t));
+}
+
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                long n, const float* __restrict__ hyper) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], gscale = hyper[5], bc1 = hyper[6], bc2_sqrt = hyper[7];
+    const float step_size = lr / bc1;
+    if (i + 3 < n) {
+        const float4 g4 = *reinterpret_cast<const float4*>(g + i);
+        float4 p4 = *reinterpret_cast<float4*>(p + i), m4 = *reinterpret_cast<float4*>(m + i), v4 = *reinterpret_cast<float4*>(v + i);
+        float gr[4] = {g4.x, g4.y, g4.z, g4.w}, pv[4] = {p4.x, p4.y, p4.z, p4.w}, mk[4] = {m4.x, m4.y, m4.z, m4.w}, vk[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gk = gr[k] * gscale;
+            if (wd != 0.f) gk += wd * pv[k];
+            mk[k] = b1 * mk[k] + (1.f - b1) * gk;
+            vk[k] = b2 * vk[k] + (1.f - b2) * gk * gk;
+            const float denom = sqrtf(vk[k]) / bc2_sqrt + eps;
+            pv[k] = pv[k] - step_size * (mk[k] / denom);
+        }
+        *reinterpret_cast<float4*>(p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+        *reinterpret_cast<float4*>(m + i) = make_float4(mk[0], mk[1], mk[2], mk[3]);
+        *reinterpret_cast<float4*>(v + i) = make_float4(vk[0], vk[1], vk[2], vk[3]);
+    } else {
+        for (long k = i; k < n; ++k) {
+            float gk = g[k] * gscale;
+            const float pv = p[k];
+            if (wd != 0.f) gk += wd * pv;
+            const float mk = b1 * m[k] + (1.f - b1) * gk;
+            const float vk = b2 * v[k] + (1.f - b2) * gk * gk;
+            m[k] = mk; v[k] = vk;
+            const float denom = sqrtf(vk) / bc2_sqrt + eps;
+            p[k] = pv - step_size * (mk / denom);
+        }
+    }
+}
+
 __global__ void fill_kernel(float* __restrict__ dst, float v, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = v;
@@ -159,11 +224,17 @@ extern "C" int mpn_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void
     return mpn_launch_status();
 }
 
+extern "C" int mpn_cast_f32(const float* src, void* dst, int64_t n, int dtype, void* stream) {
+    MPN_CHECK_ARG(src && dst && n > 0 && (dtype == MPN_BF16 || dtype == MPN_F16));
+    if (dtype == MPN_BF16) hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(nblk(n, 2048)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, (long)n);
+    else hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(nblk(n, 2048)), dim3(256), 0, (hipStream_t)stream, src, (f16_t*)dst, (long)n);
+    return mpn_launch_status();
+}
+
 extern "C" int mpn_weight_transpose(const float* w, void* wt, int Cout, int RS, int Cin, int Cout_pad, int dtype, void* stream) {
     MPN_CHECK_ARG(w && wt && Cout > 0 && RS > 0 && Cin > 0 && Cout_pad >= Cout);
     dim3 grid((Cin + 31) / 32, (Cout_pad + 31) / 32, RS), block(32, 8);
-    if (dtype == MPN_F32) hipLaunchKernelGGL(weight_transpose_kernel<float>, grid, block, 0, (hipStream_t)stream, w, (float*)wt, Cout, RS, Cin, Cout_pad);
-    else hipLaunchKernelGGL(weight_transpose_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, w, (bf16_t*)wt, Cout, RS, Cin, Cout_pad);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((weight_transpose_kernel<T>), grid, block, 0, (hipStream_t)stream, w, (T*)wt, Cout, RS, Cin, Cout_pad));
     return mpn_launch_status();
 }
 
@@ -171,24 +242,21 @@ extern "C" int mpn_weight_transpose_batched(const float* arena, void* dst, const
                                             int dtype, void* stream) {
     MPN_CHECK_ARG(arena && dst && table && nlayers > 0 && nblocks > 0 && nblocks < 0x7fffffffLL);
     dim3 grid((unsigned)nblocks), block(32, 8);
-    if (dtype == MPN_F32) hipLaunchKernelGGL(weight_transpose_batched_kernel<float>, grid, block, 0, (hipStream_t)stream, arena, (float*)dst, (const long*)table, nlayers);
-    else hipLaunchKernelGGL(weight_transpose_batched_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, arena, (bf16_t*)dst, (const long*)table, nlayers);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((weight_transpose_batched_kernel<T>), grid, block, 0, (hipStream_t)stream, arena, (T*)dst, (const long*)table, nlayers));
     return mpn_launch_status();
 }
 
 extern "C" int mpn_weight_pad_k(const float* w, void* dst, int Cout, int K, int Kpad, int dtype, void* stream) {
     MPN_CHECK_ARG(w && dst && Cout > 0 && K > 0 && Kpad >= K);
     const long n = (long)Cout * Kpad;
-    if (dtype == MPN_F32) hipLaunchKernelGGL(weight_pad_k_kernel<float>, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (float*)dst, Cout, K, Kpad);
-    else hipLaunchKernelGGL(weight_pad_k_kernel<bf16_t>, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst, Cout, K, Kpad);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((weight_pad_k_kernel<T>), dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (T*)dst, Cout, K, Kpad));
     return mpn_launch_status();
 }
 
 extern "C" int mpn_stem_pack_weight(const float* w, void* packed, int Cout, int dtype, void* stream) {
     MPN_CHECK_ARG(w && packed && Cout > 0);
     const long n = (long)Cout * 7 * 32;
-    if (dtype == MPN_F32) hipLaunchKernelGGL(stem_pack_weight_kernel<float>, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (float*)packed, Cout);
-    else hipLaunchKernelGGL(stem_pack_weight_kernel<bf16_t>, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)packed, Cout);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((stem_pack_weight_kernel<T>), dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, w, (T*)packed, Cout));
     return mpn_launch_status();
 }
 
@@ -202,8 +270,7 @@ extern "C" int mpn_stem_pack_image(const float* img, int64_t sB, int64_t sC, int
                                    int B, int H, int W, int dtype, void* stream) {
     MPN_CHECK_ARG(img && dst && B > 0 && H > 0 && W > 0);
     const long n = (long)B * (H + 6) * (W + 8);
-    if (dtype == MPN_F32) hipLaunchKernelGGL(stem_pack_image_kernel<float>, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, img, (long)sB, (long)sC, (long)sH, (long)sW, (float*)dst, B, H, W);
-    else hipLaunchKernelGGL(stem_pack_image_kernel<bf16_t>, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, img, (long)sB, (long)sC, (long)sH, (long)sW, (bf16_t*)dst, B, H, W);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((stem_pack_image_kernel<T>), dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, img, (long)sB, (long)sC, (long)sH, (long)sW, (T*)dst, B, H, W));
     return mpn_launch_status();
 }
 
@@ -216,10 +283,24 @@ extern "C" int mpn_adam_step(float* param, const float* grad, float* exp_avg, fl
     return mpn_launch_status();
 }
 
+extern "C" int mpn_adam_advance(float* hyper, void* stream) {
+    MPN_CHECK_ARG(hyper);
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hyper);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper,
+                                 void* stream) {
+    MPN_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && hyper && n > 0);
+    MPN_CHECK_ARG(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(nblk(n, 1024)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, (long)n, hyper);
+    return mpn_launch_status();
+}
+
 extern "C" int mpn_fill_f32(float* dst, float v, int64_t n, void* stream) {
     MPN_CHECK_ARG(dst && n > 0);
     hipLaunchKernelGGL(fill_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, dst, v, (long)n);
     return mpn_launch_status();
 }
 
-extern "C" const char* mpn_version(void) { return "mpn-hip 0.1 (gfx950)"; }
+extern "C" const char* mpn_version(void) { return "mpn-hip 0.2 (gfx950) src:" MPN_BUILD_ID; }

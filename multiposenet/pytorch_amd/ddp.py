@@ -39,7 +39,10 @@ class GradReducer(object):
         self.launched = 0
         backend = dist.get_backend(process_group)
         self.use_avg = backend == "nccl"
+        # gloo (debug / single-GPU tests) reduces host memory: device buckets are staged through pinned buffers
+        self.stage_host = backend != "nccl" and arena.device.type == "cuda"
         self.launch_stream = None      # set by the engine when weight gradients are produced on a side stream
+        self._trainable_sig = tuple(p.requires_grad for p in arena.params)
 
     def _build(self):
         ar = self.arena
@@ -71,6 +74,12 @@ class GradReducer(object):
 
     # ---- called by the engine -------------------------------------------------------------------
     def begin(self):
+        if tuple(p.requires_grad for p in self.arena.params) != self._trainable_sig:
+            # parameters were (un)frozen after attach(): buckets cover trainable parameters only, so rebuild them — the
+            # same change must be made on every rank (the bucket list is the collective schedule)
+            self.buckets, self.param_bucket = [], {}
+            self._build()
+            self._trainable_sig = tuple(p.requires_grad for p in self.arena.params)
         for bk in self.buckets:
             bk["pending"] = len(bk["params"])
         self.handles = []
@@ -89,6 +98,15 @@ class GradReducer(object):
     def _launch(self, bk):
         view = self.arena.grad_flat[bk["start"]: bk["end"]]
         op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
+        if self.stage_host:
+            if self.launch_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.launch_stream)
+            host = view.cpu()                       # synchronises with the producing kernels
+            h = dist.all_reduce(host, op=op, group=self.pg, async_op=True)
+            self.handles.append((h, (view, host)))
+            self.launched += 1
+            bk["pending"] = -1
+            return
         if self.launch_stream is not None:
             # the bucket's gradients come from two streams (wgrad on the side stream, BN/bias pieces on the main one):
             # order the collective after both without stalling the main stream
@@ -111,7 +129,10 @@ class GradReducer(object):
                 self._launch(bk)
         for h, view in self.handles:
             h.wait()
-            if not self.use_avg:
+            if isinstance(view, tuple):             # host-staged bucket (gloo with device gradients)
+                view, host = view
+                view.copy_(host.mul_(1.0 / self.world))
+            elif not self.use_avg:
                 view.mul_(1.0 / self.world)
         self.handles = []
 

@@ -113,9 +113,17 @@ class Engine(object):
     def w_fwd(self, layer):
         """Forward operand [Cout][R][S][Cin] in the compute dtype (a view, never a copy in f32)."""
         ar = self.m._arena
+        w = layer.weight
+        kc = 32 if ops.is16(self.cdt) else 16
+        if w.dim() == 2 and w.shape[1] % kc != 0:
+            # Linear layer whose fan-in is not a whole number of 64-byte K chunks (PRN with prn_coeff 1 or 3): zero-padded rows
+            K, Kp = w.shape[1], round_up(w.shape[1], kc)
+            dst = torch.empty((w.shape[0], Kp), dtype=self.cdt, device=w.device)
+            call("mpn_weight_pad_k", ops.ptr(ar.data_seg(w)), ops.ptr(dst), w.shape[0], K, Kp, ops.dtype_code(self.cdt), ops.stream_ptr())
+            return dst
         if self.cdt == torch.float32:
             return ar.data_seg(layer.weight)
-        return ar.data_seg(layer.weight, ar.bf16)
+        return ar.data_seg(layer.weight, ar.lowp[self.cdt])
 
     def _wt_plan(self):
         """Layout of every conv / linear layer's dgrad operand Wt[Cin][R][S][Cout_pad] inside one buffer, plus the device
@@ -124,7 +132,7 @@ class Engine(object):
         plan = self._wt_plan_cache
         if plan is not None and plan["arena"] is ar and plan["dtype"] == self.cdt:
             return plan
-        kc = 32 if self.cdt == torch.bfloat16 else 16
+        kc = 32 if ops.is16(self.cdt) else 16
         rows, views, off, blk = [], {}, 0, 0
         stem = self.m.fpn.conv1.weight
         for mod in self.m.modules():
@@ -155,7 +163,7 @@ class Engine(object):
         plan = self._wt_plan()
         if key not in plan["views"]:          # not an arena conv/linear weight: single transpose
             O, I, R, S, _, _ = _geom(layer)
-            kc = 32 if self.cdt == torch.bfloat16 else 16
+            kc = 32 if ops.is16(self.cdt) else 16
             opad = round_up(O, kc)
             wt = torch.empty((I, R, S, opad), dtype=self.cdt, device=layer.weight.device)
             ops.weight_transpose(self.m._arena.data_seg(layer.weight), wt, O, R * S, I, opad)
@@ -530,6 +538,7 @@ class Engine(object):
     def run_backward(self, ctx, out_grads):
         m = self.m
         ctx.out_grads = out_grads
+        ops.check_device(m._arena.flat)
         m._arena.ensure_grads()
         dev = m._arena.flat.device
         side = self.side_stream(dev)

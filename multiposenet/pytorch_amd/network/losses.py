@@ -149,8 +149,11 @@ class LazyFloat(numbers.Real):
     def __pow__(self, o): return float(self) ** o
     def __rpow__(self, o): return o ** float(self)
     def __eq__(self, o): return float(self) == o
+    def __ne__(self, o): return float(self) != o
     def __lt__(self, o): return float(self) < o
     def __le__(self, o): return float(self) <= o
+    def __gt__(self, o): return float(self) > o
+    def __ge__(self, o): return float(self) >= o
 
 
 LAZY_LOG = os.environ.get("MPN_LAZY_LOG", "0") == "1"
@@ -164,8 +167,22 @@ def set_lazy_log(on=True):
     LAZY_LOG = bool(on)
 
 
+class _Deferred(object):
+    """Placeholder for log value `i` of captured vector `slot` (graph.py turns it into a float / LazyFloat per replay)."""
+    __slots__ = ("slot", "i")
+
+    def __init__(self, slot, i):
+        self.slot, self.i = slot, i
+
+
+CAPTURE_LOG = None      # list of static device vectors while graph.py captures a step (no D2H copy inside a capture)
+
+
 def _log_values(t):
     """Python-visible values of a small device vector: floats (default) or LazyFloat proxies (set_lazy_log)."""
+    if CAPTURE_LOG is not None:
+        CAPTURE_LOG.append(t)
+        return [_Deferred(len(CAPTURE_LOG) - 1, i) for i in range(t.numel())]
     if not LAZY_LOG or not t.is_cuda:
         return t.detach().cpu().tolist()
     src = _LazyVec(t)

@@ -247,17 +247,20 @@ class poseNet(nn.Module):
     def _prepare(self, img):
         if not img.is_cuda:
             raise MpnError("poseNet runs on the MI355X only (input is on %s); there is no CPU path" % img.device)
+        ops.check_device(img)
         if self._arena is None or not self._arena.consistent() or self._arena.device != img.device:
             if next(self.parameters()).device != img.device:
                 raise MpnError("model parameters are on %s but the input is on %s" % (next(self.parameters()).device, img.device))
             self._build_arena(img.device)
         ar = self._arena
-        if self.compute_dtype == torch.bfloat16:
-            if ar.bf16 is None:
-                ar.bf16 = torch.empty(ar.total, dtype=torch.bfloat16, device=ar.device)
-            ops.cast_bf16(ar.flat, ar.bf16)          # one launch refreshes every forward operand
-        elif self.compute_dtype != torch.float32:
-            raise MpnError("compute_dtype must be torch.bfloat16 or torch.float32")
+        cdt = self.compute_dtype
+        if ops.is16(cdt):
+            buf = ar.lowp.get(cdt)
+            if buf is None:
+                buf = ar.lowp[cdt] = torch.empty(ar.total, dtype=cdt, device=ar.device)
+            ops.cast_lowp(ar.flat, buf)              # one launch refreshes every forward operand
+        elif cdt != torch.float32:
+            raise MpnError("compute_dtype must be torch.bfloat16, torch.float16 or torch.float32")
 
     def _want_tape(self):
         return torch.is_grad_enabled() and any(p.requires_grad for p in self._arena.params)
@@ -314,7 +317,18 @@ class poseNet(nn.Module):
         anchors = self.anchors(img_batch)
         transformed_anchors = decode_and_clip(anchors, regression, img_batch)
         results = []
-        for b in range(img_batch.shape[0] if all_images else 1):
+        if all_images:
+            # every image thresholded (posenet.py:269-271), NMS'd (:281) and gathered (:283-285) by batch-wide launches;
+            # sizes stay on the device between the stages (ops.detect_batched: two host reads per BATCH)
+            cls2 = classification.reshape(classification.shape[0], -1)
+            for boxes, nms_scores in ops.detect_batched(transformed_anchors, cls2, 0.05, 0.5):
+                if boxes is None:
+                    results.append([torch.zeros(0), torch.zeros(0), torch.zeros(0, 4)])      # posenet.py:273-275 (CPU empties)
+                else:
+                    nms_class = torch.zeros(nms_scores.shape[0], dtype=torch.int64, device=nms_scores.device)   # single class
+                    results.append([nms_scores, nms_class, boxes])
+            return predict_keypoint, results
+        for b in range(1):
             # posenet.py:269-275: score > 0.05, early-out with the CPU empty triple
             dets, _src = ops.score_filter(transformed_anchors[b], classification[b, :, 0], 0.05)
             if dets.shape[0] == 0:
@@ -387,9 +401,13 @@ class poseNet(nn.Module):
         B = x.shape[0]
         n = prn.height * prn.width * 17
         res = x.detach().float().reshape(B, n).contiguous()
-        if self.compute_dtype == torch.bfloat16:
-            xin = torch.empty((B, 1, 1, n), dtype=torch.bfloat16, device=x.device)
-            ops.cast_bf16(res, xin)
+        npad = ops.round_up(n, 32)        # activation rows are stored padded to 32 channels (prn_coeff 1 / 3: n % 32 != 0)
+        if npad != n:
+            xin = torch.zeros((B, 1, 1, npad), dtype=self.compute_dtype, device=x.device)
+            xin[:, 0, 0, :n].copy_(res)
+        elif ops.is16(self.compute_dtype):
+            xin = torch.empty((B, 1, 1, n), dtype=self.compute_dtype, device=x.device)
+            ops.cast_lowp(res, xin)
         else:
             xin = res.view(B, 1, 1, n)
         train = torch.is_grad_enabled() and any(p.requires_grad for p in prn.parameters())
@@ -402,7 +420,7 @@ class poseNet(nn.Module):
             h = eng.dropout(ctx, h, prn.drop.p)
         o, _ = eng.conv(ctx, h, prn.dens2, out_f32=True)            # its ReLU is folded into the softmax kernel
         out = torch.empty((B, n), dtype=torch.float32, device=x.device)
-        call("mpn_add_softmax_rows", ops.ptr(o.t), ops.ptr(res), ops.ptr(out), B, n, 1, ops.stream_ptr())
+        call("mpn_add_softmax_rows", ops.ptr(o.t), o.Cs, ops.ptr(res), ops.ptr(out), B, n, 1, ops.stream_ptr())
         if ctx.train and o.needs_grad:
             def bwd():
                 g = ctx.out_grads.get("prn")
@@ -410,10 +428,13 @@ class poseNet(nn.Module):
                     return
                 g = g.reshape(B, n).float().contiguous()
                 dl = torch.empty((B, n), dtype=torch.float32, device=x.device)
-                call("mpn_softmax_rows_backward", ops.ptr(out), ops.ptr(g), ops.ptr(o.t), ops.ptr(dl), B, n, ops.stream_ptr())
-                if self.compute_dtype == torch.bfloat16:
-                    d = torch.empty((B, 1, 1, n), dtype=torch.bfloat16, device=x.device)
-                    ops.cast_bf16(dl, d)
+                call("mpn_softmax_rows_backward", ops.ptr(out), ops.ptr(g), ops.ptr(o.t), o.Cs, ops.ptr(dl), B, n, ops.stream_ptr())
+                if npad != n:
+                    d = torch.zeros((B, 1, 1, npad), dtype=self.compute_dtype, device=x.device)
+                    d[:, 0, 0, :n].copy_(dl)
+                elif ops.is16(self.compute_dtype):
+                    d = torch.empty((B, 1, 1, n), dtype=self.compute_dtype, device=x.device)
+                    ops.cast_lowp(dl, d)
                 else:
                     d = dl.view(B, 1, 1, n)
                 ctx.set_grad(o, ops.Act(d, n))

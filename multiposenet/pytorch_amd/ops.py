@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, ConvParams, WgradParams, call
+from ._lib import BF16, F16, F32, ConvParams, WgradParams, call
 
 
 def round_up(v, m):
@@ -20,6 +20,8 @@ def dtype_code(dt):
         return F32
     if dt == torch.bfloat16:
         return BF16
+    if dt == torch.float16:
+        return F16
     raise _lib.MpnError("unsupported dtype %s" % dt)
 
 
@@ -43,6 +45,17 @@ def stream_handle():
     return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
+def check_device(t):
+    """Kernels are enqueued on the CURRENT device's stream: refuse tensors that live on another GPU (the reference selects
+    the device with params.gpus[0] and never calls set_device; training/batch_processor.py here does)."""
+    if not t.is_cuda:
+        raise _lib.MpnError("tensor is on %s; the HIP path has no CPU fallback" % t.device)
+    cur = torch._C._cuda_getDevice()
+    if t.device.index != cur:
+        raise _lib.MpnError("tensor is on cuda:%d but the current device is cuda:%d — call torch.cuda.set_device(%d) "
+                            "(or run under torch.cuda.device) first" % (t.device.index, cur, t.device.index))
+
+
 def stream_obj():
     """torch.cuda.Stream to record events on (None = torch's current stream)."""
     return _STREAM_OVERRIDE[-1][1] if _STREAM_OVERRIDE else None
@@ -50,6 +63,16 @@ def stream_obj():
 
 def stream_ptr():
     return ctypes.c_void_p(stream_handle())
+
+
+def is16(dt):
+    """bf16 / f16: 32 elements per 64-byte K chunk, 8 per 16-byte vector."""
+    return dt == torch.bfloat16 or dt == torch.float16
+
+
+def dtype_name(dt):
+    """Element-type spelling rocprofv3 prints for a kernel instantiation (tools/rocprof_summary.py)."""
+    return "bf16" if dt == torch.bfloat16 else ("_Float16" if dt == torch.float16 else "float")
 
 
 def ptr(t):
@@ -128,12 +151,20 @@ class _KernelEvents(object):
 KERNEL_EVENTS = _KernelEvents()
 
 _ws = {}
+WS_EPOCH = 0          # graph.py sets a unique value while it captures: the captured launches then own their scratch buffers
+
+
+def take_epoch_workspaces(epoch):
+    """Remove and return the scratch buffers allocated under capture epoch `epoch` (the graph keeps them alive; nothing
+    outside the graph may re-grow or free them)."""
+    keys = [k for k in _ws if k[3] == epoch]
+    return [_ws.pop(k) for k in keys]
 
 
 def workspace(nbytes, device, slot=0):
     """Persistent scratch (grown geometrically); one buffer per (device, slot)."""
     # one buffer per stream as well: launches on different streams must not share (or re-grow) a scratch area
-    key = (device, slot, stream_handle() if device.type == "cuda" else 0)
+    key = (device, slot, stream_handle() if device.type == "cuda" else 0, WS_EPOCH)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         so = stream_obj()
@@ -161,7 +192,7 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
     """
     dev = x.t.device
     dt = x.t.dtype
-    Cin = cin if cin is not None else round_up(x.C, 32 if dt == torch.bfloat16 else 16)
+    Cin = cin if cin is not None else round_up(x.C, 32 if is16(dt) else 16)
     if x_geom is None:
         H, W = x.H, x.W
         sB, sH, sW = x.H * x.W * x.Cs, x.W * x.Cs, x.Cs
@@ -216,10 +247,10 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         flops = 2.0 * x.B * Ho * Wo * Cout * live * min(Cin, x.C if x_geom is None else Cin)
         # the name rocprofv3 prints for this instantiation (tools/rocprof_summary.py spelling)
         general = (scale is not None or bias is not None or res is not None or accumulate or act != 0 or Cout % tc != 0)
-        name = "conv_igemm_kernel<%s, %d, 128, %s, %s>" % ("bf16" if dt == torch.bfloat16 else "float", tc,
+        name = "conv_igemm_kernel<%s, %d, 128, %s, %s>" % (dtype_name(dt), tc,
                                                           "true" if p.out_f32 else "false", "true" if general else "false")
         if KERNEL_EVENTS.detail:
-            es = 2 if dt == torch.bfloat16 else 4
+            es = 2 if is16(dt) else 4
             byts = x.B * H * W * Cin * es + x.B * Ho * Wo * p.Cout_store * (4 if out_f32 else es) * (2 if accumulate else 1) \
                 + (x.B * Ho * Wo * p.Cout_store * es if res is not None and res_mode == 1 else 0)
             name = "%s %dx%d %d->%d @%dx%d s%d%s%s%s%s%s|%d" % (
@@ -270,11 +301,11 @@ def conv_wgrad(x, dy, dw, Cout, R, S, stride, pad, cin=None, x_geom=None, db=Non
         kid = call("mpn_conv_wgrad_kernel_id", ctypes.byref(p))
         e0 = KERNEL_EVENTS.begin()
         call("mpn_conv_wgrad_partials" if chunks > 1 else "mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
-        dts = "bf16" if dt == torch.bfloat16 else "float"
-        name = ("conv_wgrad_dma_kernel<%d, %d>" % (kid >> 16, (kid >> 4) & 0xfff) if (kid & 1)
+        dts = dtype_name(dt)
+        name = ("conv_wgrad_dma%s_kernel<%d, %d>" % ("_f16" if dt == torch.float16 else "", kid >> 16, (kid >> 4) & 0xfff) if (kid & 1)
                 else "conv_wgrad_kernel<%s, %d, %d>" % (dts, kid >> 16, (kid >> 4) & 0xfff))
         if KERNEL_EVENTS.detail:
-            es = 2 if dt == torch.bfloat16 else 4
+            es = 2 if is16(dt) else 4
             name = "wgrad %dx%d %d->%d @%dx%d s%d chunks=%d|%d" % (R, S, Cin, Cout, dy.H, dy.W, stride, chunks,
                                                                  (x.B * H * W * Cin + x.B * dy.H * dy.W * dy.Cs) * es)
         KERNEL_EVENTS.end(name, 2.0 * x.B * dy.H * dy.W * Cout * R * S * Cin, e0)
@@ -304,8 +335,12 @@ def weight_transpose(w_master, wt, Cout, RS, Cin, Cout_pad):
     call("mpn_weight_transpose", ptr(w_master), ptr(wt), Cout, RS, Cin, Cout_pad, dtype_code(wt.dtype), stream_ptr())
 
 
-def cast_bf16(src, dst):
-    call("mpn_cast_f32_to_bf16", ptr(src), ptr(dst), src.numel(), stream_ptr())
+def cast_lowp(src, dst):
+    """f32 -> bf16 / f16 copy (dst's dtype decides)."""
+    call("mpn_cast_f32", ptr(src), ptr(dst), src.numel(), dtype_code(dst.dtype), stream_ptr())
+
+
+cast_bf16 = cast_lowp
 
 
 class BNState(object):
@@ -482,6 +517,36 @@ def gather_dets(dets, keep):
     if k > 0:
         call("mpn_gather_dets", ptr(dets), ptr(keep), k, ptr(boxes), ptr(scores), stream_ptr())
     return boxes, scores
+
+
+def detect_batched(boxes, scores, score_thresh, iou_thresh, mode=0, ws_limit=4 << 30):
+    """Score filter + per-image NMS + gather for EVERY image of a batch with two host round trips per batch (the candidate
+    counts size the NMS launches, the kept counts size the returned tensors) instead of two per image.
+    boxes [B,A,4], scores [B,A] (f32, contiguous).  Returns per image (boxes[k,4], scores[k]) device tensors (views)."""
+    B, A = scores.shape[0], scores.shape[1]
+    dev = scores.device
+    dets = torch.empty((B, A, 5), dtype=torch.float32, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    call("mpn_score_filter_batched", ptr(boxes), ptr(scores), B, A, float(score_thresh), ptr(dets), None, ptr(counts), stream_ptr())
+    cnt = counts.tolist()                              # host round trip 1
+    nmax = max(cnt)
+    if nmax == 0:
+        return [(None, None)] * B
+    keep = torch.empty((B, nmax), dtype=torch.int64, device=dev)
+    num = torch.empty((B,), dtype=torch.int64, device=dev)
+    per_img = call("mpn_nms_batched_workspace_bytes", 1, nmax)
+    group = max(1, min(B, int(ws_limit // per_img)))   # bound the N x N/64 mask scratch; groups of images per launch set
+    for b0 in range(0, B, group):
+        nb = min(group, B - b0)
+        ws = workspace(per_img * nb, dev, slot=4)
+        call("mpn_nms_batched", ctypes.c_void_p(dets.data_ptr() + b0 * A * 5 * 4), A * 5, ctypes.c_void_p(counts.data_ptr() + b0 * 4), nb, nmax,
+             float(iou_thresh), mode, ctypes.c_void_p(keep.data_ptr() + b0 * nmax * 8), nmax, ctypes.c_void_p(num.data_ptr() + b0 * 8),
+             ptr(ws), stream_ptr())
+    out_boxes = torch.empty((B, nmax, 4), dtype=torch.float32, device=dev)
+    out_scores = torch.empty((B, nmax), dtype=torch.float32, device=dev)
+    call("mpn_gather_dets_batched", ptr(dets), A * 5, ptr(keep), nmax, ptr(num), B, nmax, ptr(out_boxes), ptr(out_scores), nmax, stream_ptr())
+    kept = num.tolist()                                # host round trip 2
+    return [(out_boxes[b, :k], out_scores[b, :k]) if cnt[b] > 0 else (None, None) for b, k in enumerate(kept)]
 
 
 def score_filter(boxes0, scores0, thresh):

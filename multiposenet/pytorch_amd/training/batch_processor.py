@@ -21,6 +21,7 @@ def _dev(state):
 def batch_processor(state, batch):
     subnet_name = state.params.subnet_name      # 'detection_subnet' / 'keypoint_subnet' / 'prn_subnet'
     dev = _dev(state)
+    torch.cuda.set_device(dev)         # kernels go to the current device's stream (the reference relies on device 0 being current)
     grad_ctx = torch.enable_grad() if state.model.training else torch.no_grad()
     with grad_ctx:
         if subnet_name == 'keypoint_subnet':
