@@ -42,6 +42,7 @@ class GradReducer(object):
         # gloo (debug / single-GPU tests) reduces host memory: device buckets are staged through pinned buffers
         self.stage_host = backend != "nccl" and arena.device.type == "cuda"
         self.launch_stream = None      # set by the engine when weight gradients are produced on a side stream
+        self.pre_launch = None         # engine hook: hand over side-stream work still waiting for a fork point
         self._trainable_sig = tuple(p.requires_grad for p in arena.params)
 
     def _build(self):
@@ -96,6 +97,8 @@ class GradReducer(object):
             self._launch(bk)
 
     def _launch(self, bk):
+        if self.pre_launch is not None:
+            self.pre_launch()
         view = self.arena.grad_flat[bk["start"]: bk["end"]]
         op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
         if self.stage_host:
@@ -140,11 +143,20 @@ class GradReducer(object):
 def broadcast_state(model, process_group=None, src=0):
     """One-time sync of parameters and BN buffers from ``src`` (the reference re-broadcasts every step)."""
     ar = model._arena
-    dist.broadcast(ar.flat, src=src, group=process_group)
+    staged = dist.get_backend(process_group) != "nccl" and ar.flat.is_cuda      # gloo moves host memory
+
+    def bcast(t):
+        if staged:
+            h = t.detach().cpu()
+            dist.broadcast(h, src=src, group=process_group)
+            t.detach().copy_(h)
+        else:
+            dist.broadcast(t, src=src, group=process_group)
+    bcast(ar.flat)
     for m in model.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
-            dist.broadcast(m.running_mean, src=src, group=process_group)
-            dist.broadcast(m.running_var, src=src, group=process_group)
+            bcast(m.running_mean)
+            bcast(m.running_var)
 
 
 def attach(model, process_group=None, bucket_mb=32.0, broadcast=True):

@@ -34,6 +34,7 @@ class Ctx(object):
         self.uses = {}           # id(param) -> number of pending gradient contributions
         self.bn_train_ran = False
         self.side_keep = []      # operands of side-stream launches, kept alive until the streams join
+        self.side_pending = []   # closures waiting for the next fork point (Engine.fork_every > 1)
 
     def gbuf(self, act, dtype=None):
         """Gradient buffer for ``act``: returns (Act, existed)."""
@@ -71,6 +72,9 @@ class Engine(object):
         self._side = None
         self._wt_plan_cache = None
         self.overlap_wgrad = os.environ.get("MPN_SIDE_STREAM", "1") != "0"
+        # side-stream work is handed over in groups of `fork_every` layers (one event record / wait per group): a captured
+        # hipGraph pays for every cross-stream edge, the eager tape does not care much
+        self.fork_every = max(1, int(os.environ.get("MPN_SIDE_FORK_EVERY", "1")))
 
     def side_stream(self, device):
         """Second HIP stream for weight/bias gradients.  They are off the backward critical path (only the
@@ -91,19 +95,30 @@ class Engine(object):
         if side is None:
             fn()
             return
+        ctx.side_keep.append(keep)
+        ctx.side_pending.append((fn, torch_ops))
+        if len(ctx.side_pending) >= self.fork_every:
+            self.flush_side(ctx, device)
+
+    def flush_side(self, ctx, device):
+        """Fork point: everything enqueued so far on the current stream happens-before the pending side-stream closures."""
+        if not ctx.side_pending:
+            return
+        side = self.side_stream(device)
+        pending, ctx.side_pending = ctx.side_pending, []
         ev = torch.cuda.Event()
         ev.record()
-        ctx.side_keep.append(keep)
         side.wait_event(ev)
-        if torch_ops:
-            with torch.cuda.stream(side):
+        for fn, torch_ops in pending:
+            if torch_ops:
+                with torch.cuda.stream(side):
+                    fn()
+                continue
+            ops.push_stream(side)
+            try:
                 fn()
-            return
-        ops.push_stream(side)
-        try:
-            fn()
-        finally:
-            ops.pop_stream()
+            finally:
+                ops.pop_stream()
 
     # ------------------------------------------------------------------ weights
     @property
@@ -544,11 +559,13 @@ class Engine(object):
         side = self.side_stream(dev)
         if m._reducer is not None:
             m._reducer.launch_stream = side
+            m._reducer.pre_launch = (lambda: self.flush_side(ctx, dev)) if side is not None else None
             m._reducer.begin()
         tape = ctx.tape
         while tape:
             tape.pop()()
         if side is not None:
+            self.flush_side(ctx, dev)
             torch.cuda.current_stream(dev).wait_stream(side)      # join: parameter gradients are complete
         ctx.grads.clear()
         ctx.keep = []
@@ -557,3 +574,4 @@ class Engine(object):
         ctx.wt_buf = None
         if m._reducer is not None:
             m._reducer.finish()
+            m._reducer.pre_launch = None

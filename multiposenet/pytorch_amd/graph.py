@@ -13,8 +13,9 @@ stream and join before the optimizer), the RCCL bucket all-reduces when a reduce
 Rules of the road:
   * the first ``eager_steps`` calls of a signature run eagerly (they populate caches that need host copies:
     anchors, the weight-transpose table, optimizer state); the next call captures and replays;
-  * inputs are copied into static buffers owned by the graph (a no-op when the caller passes the same
-    tensors every step, as bench.py does); ``loss`` is a static 0-dim tensor overwritten by the next replay;
+  * the tensors passed on the capturing call BECOME the graph's static inputs (they are kept, not cloned); later
+    calls copy their tensors into them — a no-op when the caller passes the same tensors every step, as bench.py
+    does.  ``loss`` is a static 0-dim tensor overwritten by the next replay;
   * log values are read AFTER the replay: plain floats by default (one host sync, the reference's
     behaviour) or ``LazyFloat`` proxies with ``losses.set_lazy_log(True)``;
   * scratch buffers and activations used inside the graph belong to it (torch's graph memory pool); a model
@@ -22,6 +23,7 @@ Rules of the road:
   * PRN training (dropout seeds are host-made) is not captured — use the eager step for 'prn_subnet'.
 """
 import itertools
+import os
 from collections import OrderedDict
 
 import torch
@@ -37,10 +39,13 @@ class _Entry(object):
 
 
 class GraphedTrainStep(object):
-    def __init__(self, model, optimizer, eager_steps=2):
+    def __init__(self, model, optimizer, eager_steps=2, fork_every=None):
         self.model = model
         self.opt = optimizer
         self.eager_steps = max(1, int(eager_steps))
+        # layers of weight-gradient work handed to the side stream per fork point inside the captured graph (every
+        # cross-stream edge of a hipGraph costs a barrier packet and a cache write-back at replay)
+        self.fork_every = int(fork_every if fork_every is not None else os.environ.get("MPN_GRAPH_FORK_EVERY", "8"))
         self._entries = {}
         self._seen = {}
         self.replays = 0
@@ -58,7 +63,7 @@ class GraphedTrainStep(object):
         m = self.model
         ar = m._arena
         return (id(ar), id(ar.grad_flat), tuple(p.requires_grad for p in ar.params),
-                tuple(b.training for b in m._bns), m.compute_dtype, id(m._reducer), m._engine.overlap_wgrad)
+                tuple(b.training for b in m._bns), m.compute_dtype, id(m._reducer), m._engine.overlap_wgrad, self.fork_every)
 
     def __call__(self, inputs, gts):
         (img, subnet), = inputs
@@ -105,6 +110,8 @@ class GraphedTrainStep(object):
         losses.CAPTURE_LOG = log_srcs
         was_on = ops.KERNEL_EVENTS.on
         ops.KERNEL_EVENTS.on = False
+        eager_fork = self.model._engine.fork_every
+        self.model._engine.fork_every = max(1, self.fork_every)
         try:
             with torch.cuda.graph(graph):
                 loss, log = self._body(ent.img, subnet, ent.gts)
@@ -112,6 +119,7 @@ class GraphedTrainStep(object):
             ops.WS_EPOCH = 0
             losses.CAPTURE_LOG = None
             ops.KERNEL_EVENTS.on = was_on
+            self.model._engine.fork_every = eager_fork
         ent.graph = graph
         ent.loss = loss.detach()
         ent.log = log
