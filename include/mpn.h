@@ -299,6 +299,32 @@ int mpn_gt_heatmaps(const double* joints, const int32_t* num_people, int B, int 
 int mpn_heatmap_peaks(const float* heat, int64_t sB, int64_t sJ, int64_t sY, int64_t sX, int B, int J, int H, int W,
                       float thre1, double upsamp, int refine, double* peaks, int32_t* counts, int cap, void* stream);
 
+/* cv2.resize for float32 images / heat-map stacks (evaluate/tester.py:67,213,296-299): src element (y, x, c) at
+ * src[y*sY + x*sX + c*sC]; dst dense [Hd][Wd][C]; cubic != 0 -> INTER_CUBIC, else INTER_LINEAR (OpenCV's coordinate rule
+ * (d + 0.5)*scale - 0.5, clamped taps, horizontal then vertical pass, float32). */
+int mpn_resize(const float* src, int64_t sY, int64_t sX, int64_t sC, int Hs, int Ws, int C, float* dst, int Hd, int Wd,
+               int cubic, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pose-residual-network person assignment, device half (evaluate/tester.py:333-513; crop/gaussian helpers
+ * datasets/coco_data/prn_gaussian.py:2,134-158).
+ * mpn_prn_build_maps: for nboxes boxes (x, y, w, h doubles; box_img[b] = image of box b) and the heat-map peaks of their
+ * images (peaks [n][2] doubles grouped by image then joint type; joint_off [nimg][18] offsets) builds
+ *   occ    [nboxes][17][H][W] int32 : 1 + id of the peak assigned to the cell (id = position among its image's peaks), 0 = empty,
+ *            with the reference's inside test, float64 cell arithmetic, one-branch clamp chain and overwrite order
+ *            (tester.py:363-392); *err is set to 1 where the reference would raise IndexError;
+ *   prn_in [nboxes][H][W][17] float32: the one-hot planes blurred by skimage.filters.gaussian (sigma 1, 'nearest', 9 taps;
+ *            weights9 = the normalised kernel as scipy computes it), in scipy.ndimage.correlate1d's summation order.
+ * mpn_prn_scores: score[b][t][y][x] (where occ > 0) = sum of the N x N window of prn_out[b][:, :, t] around (y, x), clipped
+ * as prn_gaussian.crop does, in numpy's float32 pairwise order (tester.py:418-419); argmax[b][t] = first row-major maximum of
+ * the plane (tester.py:480).  H*W <= 4096.
+ * -------------------------------------------------------------------------------------------*/
+int mpn_prn_build_maps(const double* peaks, const int32_t* joint_off, const double* boxes, const int32_t* box_img, int nboxes,
+                       int H, int W, double in_thres, const double* weights9, int32_t* occ, float* prn_in, int32_t* err,
+                       void* stream);
+int mpn_prn_scores(const float* prn_out, const int32_t* occ, int nboxes, int H, int W, int N, float* score, int32_t* argmax,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

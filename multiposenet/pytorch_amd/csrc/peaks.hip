@@ -140,6 +140,51 @@ __global__ void __launch_bounds__(PK_THREADS) heatmap_peaks_kernel(const float* 
     }
 }
 
+// cv2.resize of a float32 [Hs, Ws, C] image to [Hd, Wd, C] (evaluate/tester.py:67,213,296-299): INTER_CUBIC (cubic != 0: A = -0.75,
+// four clamped taps per axis) or INTER_LINEAR (two taps; source coordinate clamped as OpenCV does), horizontal pass then
+// vertical pass, float32, left-to-right sums.  One thread per destination element.
+__global__ void resize_kernel(const float* __restrict__ src, long sY, long sX, long sC, int Hs, int Ws, int C,
+                              float* __restrict__ dst, int Hd, int Wd, int cubic) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)Hd * Wd * C) return;
+    const int c = (int)(i % C);
+    const int dx = (int)((i / C) % Wd);
+    const int dy = (int)(i / ((long)C * Wd));
+    const double scale_x = (double)Ws / (double)Wd, scale_y = (double)Hs / (double)Hd;
+    auto at = [&](int y, int x) { return src[(long)y * sY + (long)x * sX + (long)c * sC]; };
+    if (cubic) {
+        int yi[4], xi[4]; float yc[4], xc[4];
+        cubic_taps(dy, scale_y, Hs, yi, yc);
+        cubic_taps(dx, scale_x, Ws, xi, xc);
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float a = at(yi[k], xi[0]) * xc[0];
+            a = a + at(yi[k], xi[1]) * xc[1];
+            a = a + at(yi[k], xi[2]) * xc[2];
+            a = a + at(yi[k], xi[3]) * xc[3];
+            r[k] = a;
+        }
+        float v = r[0] * yc[0];
+        v = v + r[1] * yc[1];
+        v = v + r[2] * yc[2];
+        v = v + r[3] * yc[3];
+        dst[i] = v;
+    } else {
+        float fx = (float)(((double)dx + 0.5) * scale_x - 0.5), fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
+        int sx = (int)floorf(fx), sy = (int)floorf(fy);
+        fx -= (float)sx; fy -= (float)sy;
+        if (sx < 0) { fx = 0.f; sx = 0; }
+        if (sx >= Ws - 1) { fx = 0.f; sx = Ws - 1; }
+        if (sy < 0) { fy = 0.f; sy = 0; }
+        if (sy >= Hs - 1) { fy = 0.f; sy = Hs - 1; }
+        const int sx1 = sx + 1 < Ws ? sx + 1 : Ws - 1, sy1 = sy + 1 < Hs ? sy + 1 : Hs - 1;
+        const float r0 = at(sy, sx) * (1.f - fx) + at(sy, sx1) * fx;
+        const float r1 = at(sy1, sx) * (1.f - fx) + at(sy1, sx1) * fx;
+        dst[i] = r0 * (1.f - fy) + r1 * fy;
+    }
+}
+
 // ids run over the joint types of an image in order: id = (peaks of earlier joints) + slot
 __global__ void heatmap_peak_ids_kernel(double* __restrict__ peaks, const int* __restrict__ counts, int J, int cap) {
     const int b = blockIdx.x;
@@ -163,5 +208,15 @@ extern "C" int mpn_heatmap_peaks(const float* heat, int64_t sB, int64_t sJ, int6
     int rc = mpn_launch_status();
     if (rc != 0) return rc;
     hipLaunchKernelGGL(heatmap_peak_ids_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, peaks, (const int*)counts, J, cap);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_resize(const float* src, int64_t sY, int64_t sX, int64_t sC, int Hs, int Ws, int C, float* dst, int Hd, int Wd,
+                          int cubic, void* stream) {
+    MPN_CHECK_ARG(src && dst && Hs > 0 && Ws > 0 && C > 0 && Hd > 0 && Wd > 0);
+    const long n = (long)Hd * Wd * C;
+    MPN_CHECK_ARG(n < 0x7fffffffL * 256L);
+    hipLaunchKernelGGL(resize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (long)sY, (long)sX, (long)sC,
+                       Hs, Ws, C, dst, Hd, Wd, cubic);
     return mpn_launch_status();
 }

@@ -1,0 +1,164 @@
+// prn_assign.hip — device half of the pose-residual-network person assignment (evaluate/tester.py:333-513).
+//
+// The reference builds, per detected box, a 56x36x17 one-hot map of the heat-map peaks that fall inside the box
+// (tester.py:363-392), blurs every joint plane with skimage's gaussian (sigma 1, 'nearest' edges; :395-397), runs the PRN
+// once PER BOX at batch 1 (:399-406), and scores every peak by the 15x15 window sum of the PRN output around its cell
+// (:414-430) — python triple loops on the host.  Here:
+//   prn_build_maps_kernel : one workgroup per (box, joint type): cell assignment in the reference's overwrite order with its
+//                           exact float64 arithmetic and its one-branch clamp chain (including Python's negative-index wrap),
+//                           then the separable 9-tap blur in scipy.ndimage.correlate1d's summation order, written as the
+//                           float32 [box][y][x][joint] tensor the PRN consumes — all boxes of all images in ONE launch, so the
+//                           PRN forward is one batched call.
+//   prn_scores_kernel     : per (box, joint type): window sums at the occupied cells in numpy's float32 pairwise order, and
+//                           the first arg-max of the plane (the fallback of tester.py:471-483).
+// Compiled with -ffp-contract=off: results are bit-identical to the numpy/scipy arithmetic of the reference.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxCells = 4096;        // >= 56*36 (coeff 2, the only size the reference's reshape at tester.py:404 allows)
+
+__global__ void __launch_bounds__(256) prn_build_maps_kernel(const double* __restrict__ peaks,      // [n][2] (x, y), grouped by image then joint type
+                                                             const int* __restrict__ joint_off,   // [nimg][18] offsets into peaks
+                                                             const double* __restrict__ boxes,    // [nb][4] (x, y, w, h)
+                                                             const int* __restrict__ box_img,     // [nb]
+                                                             int H, int W, double in_thres, const double* __restrict__ wts /*[9]*/,
+                                                             int* __restrict__ occ,               // [nb][17][H][W]: 1 + peak id, 0 = empty
+                                                             float* __restrict__ prn_in,          // [nb][H][W][17]
+                                                             int* __restrict__ err) {
+    __shared__ int occ_s[kMaxCells];
+    __shared__ double pa[kMaxCells];
+    __shared__ double pb[kMaxCells];
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int img = box_img[b];
+    const int n = H * W;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) occ_s[i] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double bx = boxes[b * 4 + 0], by = boxes[b * 4 + 1], bw = boxes[b * 4 + 2], bh = boxes[b * 4 + 3];
+        const int* off = joint_off + img * 18;
+        const int first = off[0];
+        const double lo_x = bx - bw * in_thres, lo_y = by - bh * in_thres;
+        const double hi_x = bx + bw * (1.0 + in_thres), hi_y = by + bh * (1.0 + in_thres);
+        const double x_scale = (double)W / ceil(bw), y_scale = (double)H / ceil(bh);       // tester.py:374-375
+        for (int p = off[t]; p < off[t + 1]; ++p) {                                        // instances in annotation order: later ones overwrite
+            const double px = peaks[p * 2 + 0], py = peaks[p * 2 + 1];
+            if (!(px > lo_x && py > lo_y && px < hi_x && py < hi_y)) continue;             // tester.py:369-372
+            int x0 = (int)((px - bx) * x_scale), y0 = (int)((py - by) * y_scale);          // int(): truncation toward zero
+            if (x0 >= W && y0 >= H) { x0 = W - 1; y0 = H - 1; }                            // ONE branch of the chain applies (tester.py:378-390)
+            else if (x0 >= W) x0 = W - 1;
+            else if (y0 >= H) y0 = H - 1;
+            else if (x0 < 0 && y0 < 0) { x0 = 0; y0 = 0; }
+            else if (x0 < 0) x0 = 0;
+            else if (y0 < 0) y0 = 0;
+            if (x0 < 0) x0 += W;                                                           // numpy negative index wraps
+            if (y0 < 0) y0 += H;
+            if (x0 < 0 || x0 >= W || y0 < 0 || y0 >= H) { atomicExch(err, 1); continue; }   // IndexError in the reference
+            occ_s[y0 * W + x0] = p - first + 1;
+        }
+    }
+    __syncthreads();
+    double w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = wts[k];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) pa[i] = occ_s[i] ? 1.0 : 0.0;
+    __syncthreads();
+    // axis 0 (rows), 'nearest' extension, scipy's symmetric-kernel order: centre, then pairs from the far tap inwards
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int y = i / W, x = i - y * W;
+        double tmp = pa[i] * w[4];
+#pragma unroll
+        for (int jj = -4; jj < 0; ++jj) {
+            int ya = y + jj, yb = y - jj;
+            ya = ya < 0 ? 0 : ya; yb = yb >= H ? H - 1 : yb;
+            tmp += (pa[ya * W + x] + pa[yb * W + x]) * w[4 + jj];
+        }
+        pb[i] = tmp;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int y = i / W, x = i - y * W;
+        double tmp = pb[i] * w[4];
+#pragma unroll
+        for (int jj = -4; jj < 0; ++jj) {
+            int xa = x + jj, xb = x - jj;
+            xa = xa < 0 ? 0 : xa; xb = xb >= W ? W - 1 : xb;
+            tmp += (pb[y * W + xa] + pb[y * W + xb]) * w[4 + jj];
+        }
+        prn_in[((long)b * n + i) * 17 + t] = (float)tmp;
+        occ[((long)b * 17 + t) * n + i] = occ_s[i];
+    }
+}
+
+// numpy's float32 pairwise sum of n (<= 128) strided values (numpy/core/src/umath/loops_utils.h.src: @TYPE@_pairwise_sum)
+__device__ __forceinline__ float np_pairwise_sum(const float* a, int n, int stride) {
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; ++i) res += a[i * stride];
+        return res;
+    }
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = a[j * stride];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += a[(i + j) * stride];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i * stride];
+    return res;
+}
+
+__global__ void __launch_bounds__(64) prn_scores_kernel(const float* __restrict__ prn_out,     // [nb][H][W][17]
+                                                        const int* __restrict__ occ,          // [nb][17][H][W]
+                                                        int H, int W, int N,
+                                                        float* __restrict__ score,            // [nb][17][H][W], valid where occ > 0
+                                                        int* __restrict__ argmax) {           // [nb][17] first row-major maximum
+    const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int n = H * W;
+    const float* plane = prn_out + (long)b * n * 17 + t;           // element (y, x) at plane[(y*W + x) * 17]
+    const int* oc = occ + ((long)b * 17 + t) * n;
+    float* sc = score + ((long)b * 17 + t) * n;
+    const int half = (N - 1) / 2;
+    float best = -INFINITY;
+    int best_i = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) {
+        const float v = plane[(long)i * 17];
+        if (v > best) { best = v; best_i = i; }                    // lanes scan ascending indices: first maximum per lane
+        if (oc[i] > 0) {
+            const int y = i / W, x = i - y * W;
+            // crop(img, (y, x), N) of prn_gaussian.py:134-158: rows [y-half, y+half], cols [x-half, x+half], clipped
+            const int r0 = y - half < 0 ? 0 : y - half, r1 = y + half + 1 > H - 1 ? H : y + half + 1;
+            const int c0 = x - half < 0 ? 0 : x - half, c1 = x + half + 1 > W - 1 ? W : x + half + 1;
+            float acc = 0.f;
+            for (int r = r0; r < r1; ++r) acc = acc + np_pairwise_sum(plane + (long)(r * W + c0) * 17, c1 - c0, 17);
+            sc[i] = acc;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = __shfl_xor(best, m, 64);
+        const int oi = __shfl_xor(best_i, m, 64);
+        if (ov > best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+    }
+    if (lane == 0) argmax[b * 17 + t] = best_i;
+}
+
+}  // namespace
+
+extern "C" int mpn_prn_build_maps(const double* peaks, const int32_t* joint_off, const double* boxes, const int32_t* box_img, int nboxes,
+                                  int H, int W, double in_thres, const double* weights9, int32_t* occ, float* prn_in, int32_t* err,
+                                  void* stream) {
+    MPN_CHECK_ARG(peaks && joint_off && boxes && box_img && weights9 && occ && prn_in && err && nboxes > 0 && H > 0 && W > 0);
+    if ((long)H * W > kMaxCells) return MPN_E_UNSUPPORTED;
+    hipLaunchKernelGGL(prn_build_maps_kernel, dim3(17, nboxes), dim3(256), 0, (hipStream_t)stream, peaks, joint_off, boxes, box_img, H, W,
+                       in_thres, weights9, occ, prn_in, err);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_prn_scores(const float* prn_out, const int32_t* occ, int nboxes, int H, int W, int N, float* score, int32_t* argmax,
+                              void* stream) {
+    MPN_CHECK_ARG(prn_out && occ && score && argmax && nboxes > 0 && H > 0 && W > 0 && N > 0 && N <= 127 && (N & 1));
+    hipLaunchKernelGGL(prn_scores_kernel, dim3(17, nboxes), dim3(64), 0, (hipStream_t)stream, prn_out, occ, H, W, N, score, argmax);
+    return mpn_launch_status();
+}

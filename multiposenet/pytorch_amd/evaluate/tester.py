@@ -1,0 +1,209 @@
+"""Tester — the reference's inference drivers (``evaluate/tester.py``) over the MI355X path.
+
+    tester = Tester(model, TestParams())                       # loads params.ckpt (HDF5), eval mode, frozen BN (:105-129)
+    results = tester.infer_image(img, 'name.jpg')              # body of Tester.test() for one image (:200-239)
+    results = tester.infer_image_multiscale(img, 'name.jpg', image_id)    # body of Tester.coco_eval() for one image (:143-175):
+                                                                # 5 scales x {original, flipped} test-time augmentation
+
+``img`` is the decoded image the reference gets from ``cv2.imread(...).astype(np.float32)``: [H, W, 3] BGR, 0..255.  Decoding
+and the COCO tools (cv2.imread, pycocotools: tester.py:133-139,176-191) stay with the caller — neither library exists in
+this image.  Everything between the decoded image and the result dicts runs on the device: OpenCV-rule resizes
+(csrc/peaks.hip: mpn_resize), the network, heat-map averaging, peak extraction (network/joint_utils.py) and the PRN
+assignment (prn_process.py).  ``cv2.resize`` is restated, not linked: parity with OpenCV is unpinned (no cv2 here), see
+DESIGN.md.
+"""
+import logging
+
+import numpy as np
+import torch
+
+from .. import ops
+from .._lib import call
+from ..network import net_utils
+from ..network.joint_utils import get_joint_list
+from .prn_process import prn_process
+
+logger = logging.getLogger("multiposenet")
+
+# COCO order of the 17 keypoints (tester.py:140) and the left/right swap of the 18 heat-map channels (tester.py:326-327)
+COCO_ORDER = [0, 14, 13, 16, 15, 4, 1, 5, 2, 6, 3, 10, 7, 11, 8, 12, 9]
+SWAP_HEAT = [0, 1, 5, 6, 7, 2, 3, 4, 11, 12, 13, 8, 9, 10, 15, 14, 17, 16]
+
+
+class TestParams(object):
+    """tester.py:85-103."""
+    trunk = 'resnet101'
+    coeff = 2
+    in_thres = 0.21
+    testdata_dir = './demo/test_images/'
+    testresult_dir = './demo/output/'
+    testresult_write_image = False
+    testresult_write_json = False
+    gpus = [0]
+    ckpt = './demo/models/ckpt_baseline_resnet101.h5'
+    coco_root = 'coco_root/'
+    coco_result_filename = './extra/multipose_coco2017_results.json'
+    inp_size = 480
+    exp_name = 'multipose101'
+    subnet_name = 'keypoint_subnet'
+    batch_size = 32
+    print_freq = 20
+
+
+def resize(img, out_hw, cubic):
+    """cv2.resize(img, (out_w, out_h), interpolation=INTER_CUBIC if cubic else INTER_LINEAR) for a CUDA float32 [H, W, C] tensor."""
+    H, W, C = img.shape
+    Hd, Wd = int(out_hw[0]), int(out_hw[1])
+    out = torch.empty((Hd, Wd, C), dtype=torch.float32, device=img.device)
+    call("mpn_resize", ops.ptr(img), img.stride(0), img.stride(1), img.stride(2), H, W, C, ops.ptr(out), Hd, Wd, 1 if cubic else 0, ops.stream_ptr())
+    return out
+
+
+def _round_half_even(v):
+    return int(np.rint(v))          # cv::saturate_cast<int> of a double = cvRound
+
+
+def crop_with_factor(im, dest_size, factor=32, pad_val=0, basedon='min'):
+    """tester.py:38-82 for a CUDA [H, W, C] tensor: scale so that the chosen side becomes dest_size (cv2.resize with fx = fy =
+    scale, bilinear), pad bottom/right with pad_val to a multiple of `factor`.  Returns (padded, scale, unpadded shape)."""
+    h0, w0 = im.shape[0], im.shape[1]
+    base = {'min': min(h0, w0), 'max': max(h0, w0), 'w': w0, 'h': h0}.get(basedon, min(h0, w0))
+    im_scale = float(dest_size) / base
+    h, w = _round_half_even(h0 * im_scale), _round_half_even(w0 * im_scale)       # dsize = round(src * f)
+    scaled = resize(im, (h, w), cubic=False)
+    new_h, new_w = int(np.ceil(float(h) / factor)) * factor, int(np.ceil(float(w) / factor)) * factor
+    padded = torch.full((new_h, new_w, im.shape[2]), float(pad_val), dtype=torch.float32, device=im.device)
+    padded[:h, :w] = scaled
+    return padded, im_scale, (h, w, im.shape[2])
+
+
+def resnet_preprocess(image):
+    """datasets/coco_data/preprocessing.py:14-25 on the device: BGR 0..255 [H,W,3] -> RGB, /255, ImageNet mean/std, [3,H,W]."""
+    img = image.float() / 255.
+    img = img.flip(2)
+    mean = torch.tensor([0.485, 0.456, 0.406], dtype=torch.float32, device=img.device)
+    std = torch.tensor([0.229, 0.224, 0.225], dtype=torch.float32, device=img.device)
+    return ((img - mean) / std).permute(2, 0, 1).contiguous()
+
+
+def _to_device_image(img, dev):
+    if isinstance(img, np.ndarray):
+        img = torch.from_numpy(np.ascontiguousarray(img))
+    return img.to(dev).float()
+
+
+class Tester(object):
+    TestParams = TestParams
+
+    def __init__(self, model, train_params, batch_processor=None, val_data=None):
+        assert isinstance(train_params, TestParams)
+        self.params = train_params
+        self.val_data = val_data
+        self.batch_processor = batch_processor
+        self.model = model
+        if self.params.ckpt is not None:
+            self._load_ckpt(self.params.ckpt)
+            logger.info('Load ckpt from {}'.format(self.params.ckpt))
+        self.dev = torch.device('cuda', self.params.gpus[0])
+        torch.cuda.set_device(self.dev)
+        self.model = self.model.to(self.dev)
+        self.model.eval()
+        self.model.freeze_bn()
+
+    def _load_ckpt(self, ckpt):
+        _, _ = net_utils.load_net(ckpt, self.model, load_state_dict=True)
+
+    # ------------------------------------------------------------------ shared pieces
+    def _boxes(self, scores, classification, transformed_anchors, scale):
+        """tester.py:228-234 / :304-310: person boxes with score > 0.5, coordinates multiplied by `scale`."""
+        if scores.numel() == 0:
+            return []
+        scores = scores.detach().cpu().numpy()
+        classification = classification.detach().cpu().numpy()
+        boxes = transformed_anchors.detach().cpu().numpy()
+        out = []
+        for j in np.where(scores > 0.5)[0]:
+            if int(classification[j]) == 0:
+                out.append((boxes[j, :] * scale).tolist())
+        return out
+
+    @staticmethod
+    def _body_joints(joint_list):
+        """tester.py:158-164 / :217-223: drop the neck (type 1), shift the later types down by one."""
+        joints = []
+        for joint in joint_list.tolist():
+            if int(joint[-1]) != 1:
+                joint[-1] = max(0, int(joint[-1]) - 1)
+                joints.append(joint)
+        return joints
+
+    def prn_process(self, kps, bbox_list, file_name, image_id=0):
+        return prn_process(self.model, kps, bbox_list, file_name, image_id, coeff=self.params.coeff, in_thres=self.params.in_thres)
+
+    # ------------------------------------------------------------------ single scale (Tester.test, :194-245)
+    def infer_image(self, img, file_name='', image_id=0):
+        img = _to_device_image(img, self.dev)
+        shape_dst = max(img.shape[0], img.shape[1])
+        scale = float(shape_dst) / self.params.inp_size
+        pad = abs(img.shape[1] - img.shape[0])
+        sq = torch.zeros((img.shape[0] + pad, img.shape[1] + pad, 3), dtype=torch.float32, device=self.dev)
+        sq[:img.shape[0], :img.shape[1]] = img                                    # np.pad(..., 'constant')
+        sq = sq[:shape_dst, :shape_dst]
+        img_resized = resize(sq, (self.params.inp_size, self.params.inp_size), cubic=False)
+        img_input = resnet_preprocess(img_resized)[None]
+        with torch.no_grad():
+            heatmaps, (scores, classification, transformed_anchors) = self.model([img_input, 'both'])
+        param = {'thre1': 0.1, 'thre2': 0.05, 'thre3': 0.5}
+        joint_list = get_joint_list(img_resized, param, heatmaps[0].permute(1, 2, 0), scale)
+        bboxs = self._boxes(scores, classification, transformed_anchors, scale)
+        return self.prn_process(self._body_joints(joint_list), bboxs, file_name, image_id)
+
+    def test(self, images):
+        """tester.py:194-245 over decoded images: ``images`` maps file name -> [H, W, 3] BGR array."""
+        out = []
+        for name, img in images.items():
+            out.extend(self.infer_image(img, name))
+        return out
+
+    # ------------------------------------------------------------------ multi-scale + flip (Tester.coco_eval, :143-175)
+    def _get_multiplier(self, img):
+        """tester.py:256-262."""
+        return [x * self.params.inp_size / float(img.shape[0]) for x in [0.5, 1., 1.5, 2, 2.5]]
+
+    def _get_outputs(self, multiplier, img):
+        """tester.py:264-313: heat-maps of every scale resized back to the image and averaged; boxes per scale."""
+        H, W = img.shape[0], img.shape[1]
+        heatmap_avg = torch.zeros((H, W, 18), dtype=torch.float32, device=self.dev)
+        bbox_all = []
+        for scale in multiplier:
+            inp_size = scale * H
+            im_cropped, im_scale, real_shape = crop_with_factor(img, inp_size, factor=32, pad_val=128)
+            im_data = resnet_preprocess(im_cropped)[None]
+            with torch.no_grad():
+                heatmaps, (scores, classification, transformed_anchors) = self.model([im_data, 'both'])
+            hm = heatmaps[0].permute(1, 2, 0)[:int(im_cropped.shape[0] / 4), :int(im_cropped.shape[1] / 4), :]
+            hm = resize(hm, (hm.shape[0] * 4, hm.shape[1] * 4), cubic=True)
+            hm = hm[0:real_shape[0], 0:real_shape[1], :]
+            hm = resize(hm, (H, W), cubic=True)
+            heatmap_avg = heatmap_avg + hm / len(multiplier)
+            bbox_all.append(self._boxes(scores, classification, transformed_anchors, 1.0 / im_scale))
+        return heatmap_avg, bbox_all
+
+    @staticmethod
+    def _handle_heat(normal_heat, flipped_heat):
+        """tester.py:315-331."""
+        return (normal_heat + flipped_heat.flip(1)[:, :, SWAP_HEAT]) / 2.
+
+    def infer_image_multiscale(self, img, file_name='', image_id=0):
+        img = _to_device_image(img, self.dev)
+        multiplier = self._get_multiplier(img)
+        orig_heat, orig_bbox_all = self._get_outputs(multiplier, img)
+        flipped_heat, _ = self._get_outputs(multiplier, img.flip(1).contiguous())
+        heatmaps = self._handle_heat(orig_heat, flipped_heat)
+        param = {'thre1': 0.1, 'thre2': 0.05, 'thre3': 0.5}
+        joint_list = get_joint_list(img, param, heatmaps[:, :, :18].contiguous(), 1)
+        results = self.prn_process(self._body_joints(joint_list), orig_bbox_all[1], file_name, image_id)
+        for result in results:                                    # tester.py:167-175: COCO keypoint order
+            kp = result['keypoints']
+            result['keypoints'] = [kp[COCO_ORDER[i] * 3 + j] for i in range(17) for j in range(3)]
+        return results

@@ -110,3 +110,51 @@ def nms_peaks(thre1, heatmaps, upsamp=1.0, refine=True):
             cnt += 1
         out.append(peaks)
     return out
+
+
+def cv_resize(img, out_hw, cubic):
+    """cv2.resize(img, (out_w, out_h), interpolation=INTER_CUBIC | INTER_LINEAR) for a float32 [H, W, C] array, restated
+    (evaluate/tester.py:67,213,296-299 call sites).  Source coordinate s = (d + 0.5) * (src/dst) - 0.5; cubic: taps
+    floor(s)-1..floor(s)+2 clamped; linear: OpenCV clamps the coordinate (s < 0 -> 0, s >= n-1 -> n-1, weight 0).
+    Horizontal then vertical pass, float32 accumulation in tap order.  PARITY UNPINNED (cv2 is not in this image)."""
+    img = np.asarray(img, dtype=np.float32)
+    Hs, Ws, C = img.shape
+    Hd, Wd = int(out_hw[0]), int(out_hw[1])
+
+    def taps(n_dst, n_src):
+        scale = float(n_src) / float(n_dst)
+        nt = 4 if cubic else 2
+        idx = np.zeros((n_dst, nt), dtype=np.int64)
+        co = np.zeros((n_dst, nt), dtype=np.float32)
+        for d in range(n_dst):
+            fx = np.float32((d + 0.5) * scale - 0.5)
+            sx = int(np.floor(fx))
+            if cubic:
+                co[d] = _cubic_coeffs(fx - np.float32(sx))
+                for k in range(4):
+                    idx[d, k] = min(max(sx - 1 + k, 0), n_src - 1)
+            else:
+                fr = np.float32(fx - np.float32(sx))
+                if sx < 0:
+                    fr, sx = np.float32(0), 0
+                if sx >= n_src - 1:
+                    fr, sx = np.float32(0), n_src - 1
+                idx[d] = (sx, min(sx + 1, n_src - 1))
+                co[d] = (np.float32(1) - fr, fr)
+        return idx, co
+
+    xi, xc = taps(Wd, Ws)
+    yi, yc = taps(Hd, Hs)
+    rows = np.zeros((Hs, Wd, C), dtype=np.float32)
+    for d in range(Wd):
+        acc = img[:, xi[d, 0], :] * xc[d, 0]
+        for k in range(1, xi.shape[1]):
+            acc = acc + img[:, xi[d, k], :] * xc[d, k]
+        rows[:, d, :] = acc
+    out = np.zeros((Hd, Wd, C), dtype=np.float32)
+    for d in range(Hd):
+        acc = rows[yi[d, 0]] * yc[d, 0]
+        for k in range(1, yi.shape[1]):
+            acc = acc + rows[yi[d, k]] * yc[d, k]
+        out[d] = acc
+    return out

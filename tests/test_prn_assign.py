@@ -1,0 +1,106 @@
+"""PRN person assignment (second half; evaluate/tester.py:333-513).
+
+CPU: the oracle restatement against outputs of the REAL ``Tester.prn_process`` (g13_prn_process.npz, made by
+tests/golden/make_golden_prn_process.py) and its gaussian against real skimage (g12_prn_gaussian.npz).
+GPU: the HIP path (maps + blur + batched PRN + window scores + arg-max, host-side greedy matching) against the same real
+reference outputs and, stage by stage, against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import gold
+
+
+def _prn_weights(model_or_shapes):
+    from oracle import weightgen
+    shapes = model_or_shapes if isinstance(model_or_shapes, dict) else {k: tuple(v.shape) for k, v in model_or_shapes.state_dict().items() if k.startswith("prn.")}
+    return weightgen.gen_state_dict(shapes, seed=3, flavour="he", skip_prefixes=())
+
+
+def _cases():
+    g = gold("g13_prn_process.npz")
+    for ci in range(int(g["ncases"])):
+        yield ci, g["kps_%d" % ci].tolist(), g["boxes_%d" % ci].tolist(), g
+
+
+def test_gaussian_restatement_against_real_skimage():
+    from oracle import prn_assign_oracle
+    g = gold("g12_prn_gaussian.npz")
+    for m, ref in zip(g["maps"].astype(np.float64), g["blurred"]):
+        got = prn_assign_oracle.gaussian(m)
+        assert np.abs(got - ref).max() <= 1e-15                 # numpy's exp differs by an ulp between the two interpreters
+        assert np.array_equal(got.astype(np.float32), ref.astype(np.float32))      # identical once the PRN's float32 input is formed
+
+
+def test_oracle_against_the_real_prn_process():
+    from oracle import posenet_oracle as po, prn_assign_oracle
+    n = 56 * 36 * 17
+    shapes = {"prn.dens1.weight": (1024, n), "prn.dens1.bias": (1024,), "prn.bneck.weight": (1024, 1024), "prn.bneck.bias": (1024,),
+              "prn.dens2.weight": (n, 1024), "prn.dens2.bias": (n,)}
+    sd = {k: torch.from_numpy(v) for k, v in _prn_weights(shapes).items()}
+
+    def fwd(x):
+        with torch.no_grad():
+            return po.prn_forward(sd, torch.from_numpy(x)).numpy()
+    for ci, kps, boxes, g in _cases():
+        res = prn_assign_oracle.prn_process(fwd, kps, boxes, "img%d.jpg" % ci, ci)
+        assert len(res) == int(g["n_%d" % ci])
+        for r, kp, sc, bb in zip(res, g["keypoints_%d" % ci], g["score_%d" % ci], g["bbox_%d" % ci]):
+            assert np.array_equal(np.array(r["keypoints"]), kp) and r["score"] == sc and np.array_equal(np.array(r["bbox"]), bb)
+            assert r["image_id"] == ci and r["file_name"] == "img%d.jpg" % ci and r["category_id"] == 1
+
+
+@pytest.mark.gpu
+def test_hip_prn_process_against_the_real_reference_and_the_oracle():
+    from multiposenet.pytorch_amd.evaluate.prn_process import _W9, prn_process, prn_process_batch
+    from multiposenet.pytorch_amd import ops
+    from multiposenet.pytorch_amd._lib import call
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    from oracle import prn_assign_oracle
+    assert torch.cuda.is_available()
+    model = poseNet(50, compute_dtype=torch.float32).cuda()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in _prn_weights(model).items()}, strict=False)
+    model.eval()
+    all_kps, all_boxes = [], []
+    for ci, kps, boxes, g in _cases():
+        all_kps.append(kps); all_boxes.append(boxes)
+        res = prn_process(model, kps, boxes, "img%d.jpg" % ci, ci)
+        assert len(res) == int(g["n_%d" % ci]), ci
+        for r, kp, sc, bb in zip(res, g["keypoints_%d" % ci], g["score_%d" % ci], g["bbox_%d" % ci]):
+            assert np.array_equal(np.array(r["keypoints"]), kp), "case %d: keypoints differ from the real reference" % ci
+            assert r["score"] == sc and np.array_equal(np.array(r["bbox"]), bb) and r["image_id"] == ci
+        # stage by stage against the oracle: cells and blur bit-exact
+        if boxes:
+            peaks, bboxes, old, inp = prn_assign_oracle.build_maps(kps, boxes)
+            nb = len(bboxes)
+            flat, off = [], []
+            for j in range(17):
+                off.append(len(flat)); flat.extend([p[0], p[1]] for p in peaks[j])
+            off.append(len(flat))
+            dev = "cuda"
+            occ = torch.empty((nb, 17, 56, 36), dtype=torch.int32, device=dev)
+            pin = torch.empty((nb, 56, 36, 17), dtype=torch.float32, device=dev)
+            err = torch.zeros(1, dtype=torch.int32, device=dev)
+            call("mpn_prn_build_maps", ops.ptr(torch.tensor(flat if flat else [[0.0, 0.0]], dtype=torch.float64, device=dev)),
+                 ops.ptr(torch.tensor([off], dtype=torch.int32, device=dev)), ops.ptr(torch.tensor(bboxes, dtype=torch.float64, device=dev)),
+                 ops.ptr(torch.zeros(nb, dtype=torch.int32, device=dev)), nb, 56, 36, 0.21, ops.ptr(torch.from_numpy(_W9).to(dev)),
+                 ops.ptr(occ), ops.ptr(pin), ops.ptr(err), ops.stream_ptr())
+            want_occ = np.where(old[:, :, :, 0, :] == 1, old[:, :, :, 2, :] + 1, 0).transpose(0, 3, 1, 2)
+            assert int(err.item()) == 0 and np.array_equal(occ.cpu().numpy(), want_occ.astype(np.int32))
+            assert np.array_equal(pin.cpu().numpy(), inp.astype(np.float32)), "blurred PRN input differs from scipy's arithmetic"
+            # window sums in numpy's float32 pairwise order + first arg-max, on a random plane set
+            rs = np.random.RandomState(ci)
+            outp = rs.rand(nb, 56, 36, 17).astype(np.float32)
+            score = torch.zeros((nb, 17, 56, 36), dtype=torch.float32, device=dev)
+            amax = torch.empty((nb, 17), dtype=torch.int32, device=dev)
+            call("mpn_prn_scores", ops.ptr(torch.from_numpy(outp).to(dev)), ops.ptr(occ), nb, 56, 36, 15, ops.ptr(score), ops.ptr(amax), ops.stream_ptr())
+            sc, am, oc = score.cpu().numpy(), amax.cpu().numpy(), occ.cpu().numpy()
+            for b, t_, y, x in np.argwhere(oc > 0):
+                assert sc[b, t_, y, x] == np.sum(prn_assign_oracle.crop(outp[b, :, :, t_], (y, x), N=15)), "window sum is not numpy's"
+            assert np.array_equal(am, outp.reshape(nb, -1, 17).argmax(1).astype(np.int32))
+    # every image in the same launches
+    batch = prn_process_batch(model, all_kps, all_boxes, ["img%d.jpg" % i for i in range(len(all_kps))], list(range(len(all_kps))))
+    for ci, kps, boxes, g in _cases():
+        assert len(batch[ci]) == int(g["n_%d" % ci])
+        for r, kp in zip(batch[ci], g["keypoints_%d" % ci]):
+            assert np.array_equal(np.array(r["keypoints"]), kp)
