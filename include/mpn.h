@@ -316,7 +316,8 @@ int mpn_resize(const float* src, int64_t sY, int64_t sX, int64_t sC, int Hs, int
  *   prn_in [nboxes][H][W][17] float32: the one-hot planes blurred by skimage.filters.gaussian (sigma 1, 'nearest', 9 taps;
  *            weights9 = the normalised kernel as scipy computes it), in scipy.ndimage.correlate1d's summation order.
  * mpn_prn_scores: score[b][t][y][x] (where occ > 0) = sum of the N x N window of prn_out[b][:, :, t] around (y, x), clipped
- * as prn_gaussian.crop does, in numpy's float32 pairwise order (tester.py:418-419); argmax[b][t] = first row-major maximum of
+ * as prn_gaussian.crop does, in np.sum's own float32 order (pairwise over the row-major flattened window: exact ties between
+ * candidates exist and the reference resolves them by sort order; tester.py:418-419); N odd, <= 15; argmax[b][t] = first row-major maximum of
  * the plane (tester.py:480).  H*W <= 4096.
  * -------------------------------------------------------------------------------------------*/
 int mpn_prn_build_maps(const double* peaks, const int32_t* joint_off, const double* boxes, const int32_t* box_img, int nboxes,

@@ -13,7 +13,8 @@ from .._lib import MpnError, call
 from .. import ops
 
 NUM_JOINTS = 18                      # joint_utils.py:16
-DEFAULT_CAP = 256                    # peaks kept per joint type (the reference has no limit; an overflow raises)
+DEFAULT_CAP = 256                    # first-try peaks per joint type (the reference has no limit: the launch is repeated with a
+                                     # larger buffer when a plane holds more; an explicit `cap` argument is a hard limit instead)
 
 
 def _peaks_device(heat_bjhw, thre1, upsamp, refine, cap=DEFAULT_CAP):
@@ -31,6 +32,20 @@ def _peaks_device(heat_bjhw, thre1, upsamp, refine, cap=DEFAULT_CAP):
     return peaks, counts
 
 
+def _extract(heat_bjhw, thre1, upsamp, refine, cap):
+    """Peaks of every plane as host arrays; a plane with more than `cap` peaks (noise-like maps) reruns the launch with a
+    capacity that fits — the reference has no limit."""
+    grow = cap is None                      # an explicit capacity is a hard limit (overflow raises)
+    cap = DEFAULT_CAP if cap is None else cap
+    pk, cnt = _peaks_device(heat_bjhw, thre1, upsamp, refine, cap)
+    if grow:
+        most = int(cnt.max().item()) if cnt.numel() else 0
+        if most > cap:
+            cap = 1 << (most - 1).bit_length()
+            pk, cnt = _peaks_device(heat_bjhw, thre1, upsamp, refine, cap)
+    return _split(pk, cnt, cap)
+
+
 def _split(peaks, counts, cap):
     peaks, counts = peaks.cpu().numpy(), counts.cpu().numpy()          # one D2H of the compact result
     if int(counts.max(initial=0)) > cap:
@@ -40,24 +55,21 @@ def _split(peaks, counts, cap):
 
 def find_peaks(param, img):
     """joint_utils.py:19-31.  img: CUDA float32 [H, W].  Returns an int array [[x, y], ...] in row-major order."""
-    pk, cnt = _peaks_device(img[None, None], param['thre1'], 1.0, False)
-    out = _split(pk, cnt, DEFAULT_CAP)[0][0]
+    out = _extract(img[None, None], param['thre1'], 1.0, False, None)[0][0]
     return out[:, :2].astype(np.int64)
 
 
-def NMS(param, heatmaps, upsampFactor=1., bool_refine_center=True, bool_gaussian_filt=False, cap=DEFAULT_CAP):
+def NMS(param, heatmaps, upsampFactor=1., bool_refine_center=True, bool_gaussian_filt=False, cap=None):
     """joint_utils.py:61-138.  heatmaps: CUDA float32 tensor [H, W, J] (any strides, e.g. ``pred[0].permute(1, 2, 0)``).
     Returns the reference's list of J arrays [n, 4] = (x, y, score, id)."""
     if bool_gaussian_filt:
         raise MpnError("bool_gaussian_filt=True (off by default in the reference, joint_utils.py:61) is not built")
-    pk, cnt = _peaks_device(heatmaps.permute(2, 0, 1)[None], param['thre1'], upsampFactor, bool_refine_center, cap)
-    return _split(pk, cnt, cap)[0]
+    return _extract(heatmaps.permute(2, 0, 1)[None], param['thre1'], upsampFactor, bool_refine_center, cap)[0]
 
 
-def NMS_batch(param, pred, upsampFactor=1., bool_refine_center=True, cap=DEFAULT_CAP):
+def NMS_batch(param, pred, upsampFactor=1., bool_refine_center=True, cap=None):
     """All images of a ``[B, J, H, W]`` heat-map tensor in one launch; a list (per image) of NMS() results."""
-    pk, cnt = _peaks_device(pred, param['thre1'], upsampFactor, bool_refine_center, cap)
-    return _split(pk, cnt, cap)
+    return _extract(pred, param['thre1'], upsampFactor, bool_refine_center, cap)
 
 
 def get_joint_list(img_orig, param, heatmaps, scale):

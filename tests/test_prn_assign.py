@@ -81,22 +81,28 @@ def test_hip_prn_process_against_the_real_reference_and_the_oracle():
             occ = torch.empty((nb, 17, 56, 36), dtype=torch.int32, device=dev)
             pin = torch.empty((nb, 56, 36, 17), dtype=torch.float32, device=dev)
             err = torch.zeros(1, dtype=torch.int32, device=dev)
-            call("mpn_prn_build_maps", ops.ptr(torch.tensor(flat if flat else [[0.0, 0.0]], dtype=torch.float64, device=dev)),
-                 ops.ptr(torch.tensor([off], dtype=torch.int32, device=dev)), ops.ptr(torch.tensor(bboxes, dtype=torch.float64, device=dev)),
-                 ops.ptr(torch.zeros(nb, dtype=torch.int32, device=dev)), nb, 56, 36, 0.21, ops.ptr(torch.from_numpy(_W9).to(dev)),
+            # (inputs are named: a temporary handed to ops.ptr() would be freed, and its memory re-used, before the launch)
+            d_peaks = torch.tensor(flat if flat else [[0.0, 0.0]], dtype=torch.float64, device=dev)
+            d_off = torch.tensor([off], dtype=torch.int32, device=dev)
+            d_boxes = torch.tensor(bboxes, dtype=torch.float64, device=dev)
+            d_img = torch.zeros(nb, dtype=torch.int32, device=dev)
+            d_w9 = torch.from_numpy(_W9).to(dev)
+            call("mpn_prn_build_maps", ops.ptr(d_peaks), ops.ptr(d_off), ops.ptr(d_boxes), ops.ptr(d_img), nb, 56, 36, 0.21, ops.ptr(d_w9),
                  ops.ptr(occ), ops.ptr(pin), ops.ptr(err), ops.stream_ptr())
             want_occ = np.where(old[:, :, :, 0, :] == 1, old[:, :, :, 2, :] + 1, 0).transpose(0, 3, 1, 2)
             assert int(err.item()) == 0 and np.array_equal(occ.cpu().numpy(), want_occ.astype(np.int32))
             assert np.array_equal(pin.cpu().numpy(), inp.astype(np.float32)), "blurred PRN input differs from scipy's arithmetic"
-            # window sums in numpy's float32 pairwise order + first arg-max, on a random plane set
+            # window sums in np.sum's float32 pairwise order + first arg-max, on a random plane set
             rs = np.random.RandomState(ci)
             outp = rs.rand(nb, 56, 36, 17).astype(np.float32)
             score = torch.zeros((nb, 17, 56, 36), dtype=torch.float32, device=dev)
             amax = torch.empty((nb, 17), dtype=torch.int32, device=dev)
-            call("mpn_prn_scores", ops.ptr(torch.from_numpy(outp).to(dev)), ops.ptr(occ), nb, 56, 36, 15, ops.ptr(score), ops.ptr(amax), ops.stream_ptr())
+            d_out = torch.from_numpy(outp).to(dev)
+            call("mpn_prn_scores", ops.ptr(d_out), ops.ptr(occ), nb, 56, 36, 15, ops.ptr(score), ops.ptr(amax), ops.stream_ptr())
             sc, am, oc = score.cpu().numpy(), amax.cpu().numpy(), occ.cpu().numpy()
             for b, t_, y, x in np.argwhere(oc > 0):
-                assert sc[b, t_, y, x] == np.sum(prn_assign_oracle.crop(outp[b, :, :, t_], (y, x), N=15)), "window sum is not numpy's"
+                cr = prn_assign_oracle.crop(outp[b, :, :, t_], (y, x), N=15)
+                assert sc[b, t_, y, x] == np.sum(cr), "window sum is not np.sum's float32 result"
             assert np.array_equal(am, outp.reshape(nb, -1, 17).argmax(1).astype(np.int32))
     # every image in the same launches
     batch = prn_process_batch(model, all_kps, all_boxes, ["img%d.jpg" % i for i in range(len(all_kps))], list(range(len(all_kps))))
