@@ -11,8 +11,9 @@ arena overlapped with backward); weak scaling (32 images per GPU).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-The timed step is ONE hipGraph launch (multiposenet/pytorch_amd/graph.py: forward, losses, zero_grad, backward on two
-HIP streams, RCCL buckets, Adam — captured once, replayed per step; `--no-graph` times the eager tape).  Every timed
+The timed step is the recorded step of multiposenet/pytorch_amd/replay.py (forward, losses, zero_grad, backward on two
+HIP streams, RCCL buckets, Adam — recorded once as a launch list and re-issued per step (replay.py); `--launch graph`
+times a captured hipGraph instead, `--launch eager` the Python tape).  Every timed
 step is also bracketed by a pair of HIP events on the launch stream; their median is reported beside the wall-clock
 mean that `value` is computed from.
 
@@ -52,7 +53,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--eager-log", action="store_true", help="plain-float loss logs (one host sync per step, the reference's behaviour)")
-    ap.add_argument("--no-graph", action="store_true", help="time the eager Python tape instead of the captured hipGraph")
+    ap.add_argument("--launch", default="replay", choices=["replay", "graph", "eager"],
+                    help="replay: recorded launch list (replay.py, default); graph: captured hipGraph (graph.py); eager: the Python tape")
+    ap.add_argument("--no-graph", action="store_true", help="same as --launch eager")
     ap.add_argument("--instr-steps", type=int, default=2, help="instrumented eager steps per schedule after the timed region")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-baseline-worker", action="store_true")
@@ -221,9 +224,12 @@ def main():
 
     last_log = {}
     from multiposenet.pytorch_amd.graph import GraphedTrainStep
+    from multiposenet.pytorch_amd.replay import ReplayedTrainStep
     from multiposenet.pytorch_amd.training.batch_processor import train_step
     inputs, gts = [[img, "train_both"]], ["train_both", heat, wgt, anno]
-    gstep = None if args.no_graph else GraphedTrainStep(model, opt)
+    if args.no_graph:
+        args.launch = "eager"
+    gstep = {"replay": lambda: ReplayedTrainStep(model, opt), "graph": lambda: GraphedTrainStep(model, opt), "eager": lambda: None}[args.launch]()
 
     def step():
         loss, log = gstep(inputs, gts) if gstep is not None else train_step(model, opt, inputs, gts)
@@ -301,7 +307,10 @@ def main():
                                    % (args.layers, args.size, args.size, args.batch, args.dtype),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "loss_log": "eager floats (host sync per step)" if args.eager_log else "asynchronous (set_lazy_log)",
-                       "launch": "eager tape" if gstep is None else "one hipGraph replay per step (%d replays so far)" % gstep.replays},
+                       "launch": {"eager": "eager Python tape (autograd node + ~2300 ctypes launches built per step)",
+                                  "graph": "one hipGraph replay per step",
+                                  "replay": "recorded launch list re-issued per step (replay.py)"}[args.launch]
+                                 + ("" if gstep is None else ", %d replays" % gstep.replays)},
         }
         out["ms_per_step_median_hipevent"] = round(median_ms, 3)
         out["ms_per_step_min_max_hipevent"] = [round(step_ms[0], 3), round(step_ms[-1], 3)]

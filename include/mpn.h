@@ -274,6 +274,12 @@ int mpn_adam_advance(float* hyper, void* stream);
 int mpn_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper,
                       void* stream);
 int mpn_fill_f32(float* dst, float v, int64_t n, void* stream);
+/* device-to-device copy on the stream (gradient hand-over between two activations of equal geometry) */
+int mpn_copy_bytes(void* dst, const void* src, int64_t nbytes, void* stream);
+/* log vector of a recorded training step (replay.py): kp8 = out of mpn_mse_heatmap_forward (or NULL), det2 = out of
+ * mpn_focal_forward (or NULL); logv[0..7] = kp8, [8] = cls + reg, [9] = cls, [10] = reg, [11] = loss (the sums the reference
+ * forms with torch adds at posenet.py:387,421 and the combined step of SURVEY.md 8d) */
+int mpn_step_log(const float* kp8, const float* det2, float* logv, void* stream);
 
 /* library self-description */
 const char* mpn_version(void);

@@ -129,6 +129,8 @@ SIGNATURES = {
     "mpn_adam_advance": (_i, [_vp, _vp]),
     "mpn_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "mpn_fill_f32": (_i, [_vp, _f, _i64, _vp]),
+    "mpn_copy_bytes": (_i, [_vp, _vp, _i64, _vp]),
+    "mpn_step_log": (_i, [_vp, _vp, _vp, _vp]),
     "mpn_version": (ctypes.c_char_p, []),
 }
 
@@ -170,11 +172,28 @@ def check(status, what):
         raise MpnError("%s failed with status %d" % (what, status))
 
 
+# While replay.py records a training step every launch is appended here as (callable, args, is_c_abi): C-ABI entry points through
+# call(), torch-level stream/event operations through gpu_op().  Replaying the list re-issues exactly the same work.
+TAPE = None
+
+
 def call(name, *args):
     """Invoke a status-returning entry point and raise on failure."""
-    st = getattr(lib(), name)(*args)
+    fn = getattr(lib(), name)
+    st = fn(*args)
     if name in _COUNT_FUNCS:
         return st
     if st != 0:
         raise MpnError("%s failed with status %d" % (name, st))
+    if TAPE is not None:
+        TAPE.append((fn, args, True))
     return 0
+
+
+def gpu_op(fn, *args):
+    """A device-side operation that is not a C-ABI launch (event record / stream wait, a collective, a tiny torch op on
+    static tensors): run it and, while a step is being recorded, remember it for replay."""
+    out = fn(*args)
+    if TAPE is not None:
+        TAPE.append((fn, args, False))
+    return out

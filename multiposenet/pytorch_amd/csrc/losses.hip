@@ -458,6 +458,28 @@ extern "C" int mpn_dropout(const void* x, void* y, int64_t n, uint64_t seed, flo
     return mpn_launch_status();
 }
 
+// log vector of the combined step: [0..4] level losses, [5] heat-map total, [6] max_ht, [7] min_ht, [8] detection total
+// (cls + reg), [9] cls, [10] reg, [11] loss = heat-map total + detection total — the additions torch would do on the host side
+__global__ void step_log_kernel(const float* __restrict__ kp8, const float* __restrict__ det2, float* __restrict__ logv) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float kp_total = 0.f, det_total = 0.f;
+    if (kp8) {
+        for (int i = 0; i < 8; ++i) logv[i] = kp8[i];
+        kp_total = kp8[5];
+    }
+    if (det2) {
+        det_total = det2[0] + det2[1];
+        logv[8] = det_total; logv[9] = det2[0]; logv[10] = det2[1];
+    }
+    logv[11] = (kp8 && det2) ? kp_total + det_total : (kp8 ? kp_total : det_total);
+}
+
+extern "C" int mpn_step_log(const float* kp8, const float* det2, float* logv, void* stream) {
+    MPN_CHECK_ARG(logv && (kp8 || det2));
+    hipLaunchKernelGGL(step_log_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, kp8, det2, logv);
+    return mpn_launch_status();
+}
+
 extern "C" int mpn_bce_chunks(int64_t n) { return (int)((n + 4095) / 4096); }
 
 extern "C" int mpn_bce_mean_forward(const float* p, const float* label, int64_t n, float* partial, int chunks, float* out, void* stream) {

@@ -297,6 +297,11 @@ extern "C" int mpn_adam_step_dev(float* param, const float* grad, float* exp_avg
     return mpn_launch_status();
 }
 
+extern "C" int mpn_copy_bytes(void* dst, const void* src, int64_t nbytes, void* stream) {
+    MPN_CHECK_ARG(dst && src && nbytes > 0);
+    return (int)hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+}
+
 extern "C" int mpn_fill_f32(float* dst, float v, int64_t n, void* stream) {
     MPN_CHECK_ARG(dst && n > 0);
     hipLaunchKernelGGL(fill_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, dst, v, (long)n);

@@ -25,6 +25,8 @@ Equal shard sizes => the average of local-mean gradients equals the gradient of 
 import torch
 import torch.distributed as dist
 
+from ._lib import gpu_op
+
 
 class GradReducer(object):
     def __init__(self, arena, process_group=None, bucket_mb=32.0, param_filter=None):
@@ -94,7 +96,7 @@ class GradReducer(object):
         bk = self.buckets[b]
         bk["pending"] -= 1
         if bk["pending"] == 0:
-            self._launch(bk)
+            gpu_op(self._launch, bk)           # (recordable: replay.py re-issues the collective at this point of the step)
 
     def _launch(self, bk):
         if self.pre_launch is not None:

@@ -16,7 +16,7 @@ import os
 import torch
 
 from . import ops
-from ._lib import call
+from ._lib import call, gpu_op
 from .ops import Act, round_up
 
 
@@ -107,8 +107,8 @@ class Engine(object):
         side = self.side_stream(device)
         pending, ctx.side_pending = ctx.side_pending, []
         ev = torch.cuda.Event()
-        ev.record()
-        side.wait_event(ev)
+        gpu_op(ev.record, torch.cuda.current_stream(device))
+        gpu_op(side.wait_event, ev)
         for fn, torch_ops in pending:
             if torch_ops:
                 with torch.cuda.stream(side):
@@ -244,7 +244,7 @@ class Engine(object):
             elif existed:
                 ops.add_inplace(g, dy)
             else:
-                g.t.copy_(dy.t)
+                ops.copy_act(g, dy)
         ar = self.m._arena
         wg = layer.weight.requires_grad
         bg = bias is not None and bias.requires_grad
@@ -419,11 +419,13 @@ class Engine(object):
             def bwd():
                 dy = ctx.pop_grad(y)
                 if dy is not None:
+                    dwp = torch.empty((64, 7, 32), dtype=torch.float32, device=img.device)
+
                     def stem_wgrad():
-                        dwp = torch.zeros((64, 7, 32), dtype=torch.float32, device=img.device)
+                        call("mpn_fill_f32", ops.ptr(dwp), 0.0, dwp.numel(), ops.stream_ptr())
                         ops.conv_wgrad(xa, dy, dwp, 64, 7, 1, 2, 0, cin=32, x_geom=geom)
                         call("mpn_stem_unpack_wgrad", ops.ptr(dwp), ops.ptr(self.m._arena.grad_seg(w)), 64, ops.stream_ptr())
-                    self._on_side(ctx, dy.t.device, (xa, dy), stem_wgrad, torch_ops=True)
+                    self._on_side(ctx, dy.t.device, (xa, dy, dwp), stem_wgrad)
                 self._grad_done(ctx, w)
             ctx.tape.append(bwd)
         z = self.bn(ctx, y, st, f.bn1, True)
@@ -560,18 +562,18 @@ class Engine(object):
         if m._reducer is not None:
             m._reducer.launch_stream = side
             m._reducer.pre_launch = (lambda: self.flush_side(ctx, dev)) if side is not None else None
-            m._reducer.begin()
+            gpu_op(m._reducer.begin)
         tape = ctx.tape
         while tape:
             tape.pop()()
         if side is not None:
             self.flush_side(ctx, dev)
-            torch.cuda.current_stream(dev).wait_stream(side)      # join: parameter gradients are complete
+            gpu_op(torch.cuda.current_stream(dev).wait_stream, side)      # join: parameter gradients are complete
         ctx.grads.clear()
         ctx.keep = []
         ctx.side_keep = []
         ctx.wt.clear()
         ctx.wt_buf = None
         if m._reducer is not None:
-            m._reducer.finish()
             m._reducer.pre_launch = None
+            gpu_op(m._reducer.finish)

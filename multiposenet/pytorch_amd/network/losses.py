@@ -28,20 +28,45 @@ def _pixel_major(t):
     return g
 
 
+def mse_forward_raw(pm, heat_nhwc, wgt_nhwc):
+    """pm: five pixel-major [B,H,W,C_j] f32 predictions.  Returns the device vector out[8] (five level means, total, max, min)."""
+    B, H, W, _ = pm[0].shape
+    npix = B * H * W
+    dev = pm[0].device
+    chunks = call("mpn_mse_chunks", npix)
+    part = ops.workspace(chunks * 8 * 4, dev, slot=5)
+    out = torch.empty(8, dtype=torch.float32, device=dev)
+    call("mpn_mse_heatmap_forward", _vpx5(*[p.data_ptr() for p in pm]), _i64x5(*[p.stride(2) for p in pm]),
+         ops.ptr(heat_nhwc), ops.ptr(wgt_nhwc), npix, ops.ptr(part), chunks, ops.ptr(out), ops.stream_ptr())
+    return out
+
+
+def mse_backward_raw(pm, heat, wgt, gs, need):
+    """Gradients of the total w.r.t. the five predictions (logical [B,C,H,W] views of fresh NHWC tensors; None where
+    need[j] is false); gs: device float[1] upstream gradient."""
+    B, H, W, _ = pm[0].shape
+    npix = B * H * W
+    grads, gptr, gsp, gc = [], [], [], []
+    for j, p in enumerate(pm):
+        if need[j]:
+            g = torch.empty((B, H, W, p.shape[3]), dtype=torch.float32, device=p.device)
+            grads.append(g.permute(0, 3, 1, 2))
+            gptr.append(g.data_ptr()); gsp.append(g.stride(2)); gc.append(p.shape[3])
+        else:
+            grads.append(None)
+            gptr.append(None); gsp.append(0); gc.append(0)
+    call("mpn_mse_heatmap_backward", _vpx5(*[p.data_ptr() for p in pm]), _vpx5(*gptr), _i64x5(*[p.stride(2) for p in pm]),
+         _i64x5(*gsp), _i32x5(*gc), ops.ptr(heat), ops.ptr(wgt), npix, ops.ptr(gs), ops.stream_ptr())
+    return grads
+
+
 class _HeatmapMSE(torch.autograd.Function):
     """sum_j mean(((pred_j[:, :18] * w) - (w * gt))^2)   (posenet.py:376-387)."""
 
     @staticmethod
     def forward(ctx, heat_nhwc, wgt_nhwc, *preds):
         pm = [_pixel_major(p.detach()) for p in preds]
-        B, H, W, _ = pm[0].shape
-        npix = B * H * W
-        dev = pm[0].device
-        chunks = call("mpn_mse_chunks", npix)
-        part = ops.workspace(chunks * 8 * 4, dev, slot=5)
-        out = torch.empty(8, dtype=torch.float32, device=dev)
-        call("mpn_mse_heatmap_forward", _vpx5(*[p.data_ptr() for p in pm]), _i64x5(*[p.stride(2) for p in pm]),
-             ops.ptr(heat_nhwc), ops.ptr(wgt_nhwc), npix, ops.ptr(part), chunks, ops.ptr(out), ops.stream_ptr())
+        out = mse_forward_raw(pm, heat_nhwc, wgt_nhwc)
         ctx.pm = pm
         ctx.gt = (heat_nhwc, wgt_nhwc)
         ctx.mark_non_differentiable(out)
@@ -49,22 +74,9 @@ class _HeatmapMSE(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gtotal, _gout):
-        pm = ctx.pm
         heat, wgt = ctx.gt
-        B, H, W, _ = pm[0].shape
-        npix = B * H * W
-        grads, gptr, gsp, gc = [], [], [], []
-        for j, p in enumerate(pm):
-            if ctx.needs_input_grad[2 + j]:
-                g = torch.empty((B, H, W, p.shape[3]), dtype=torch.float32, device=p.device)
-                grads.append(g.permute(0, 3, 1, 2))
-                gptr.append(g.data_ptr()); gsp.append(g.stride(2)); gc.append(p.shape[3])
-            else:
-                grads.append(None)
-                gptr.append(None); gsp.append(0); gc.append(0)
         gs = gtotal.detach().reshape(1).float().contiguous()
-        call("mpn_mse_heatmap_backward", _vpx5(*[p.data_ptr() for p in pm]), _vpx5(*gptr), _i64x5(*[p.stride(2) for p in pm]),
-             _i64x5(*gsp), _i32x5(*gc), ops.ptr(heat), ops.ptr(wgt), npix, ops.ptr(gs), ops.stream_ptr())
+        grads = mse_backward_raw(ctx.pm, heat, wgt, gs, [ctx.needs_input_grad[2 + j] for j in range(len(ctx.pm))])
         return (None, None) + tuple(grads)
 
 
@@ -214,39 +226,50 @@ def build_keypoint_loss(saved_for_loss, heat_temp, heat_weight):
     return total, log
 
 
+def focal_forward_raw(cls, reg, anchors, anno):
+    """Returns (out[2] = {classification loss, regression loss}, saved operands for focal_backward_raw)."""
+    B, A = cls.shape[0], cls.shape[1]
+    if cls.shape[2] != 1:
+        raise NotImplementedError("the hot path is single-class (posenet.py:189 num_classes=1)")
+    dev = cls.device
+    c = cls.detach().float().contiguous()
+    r = reg.detach().float().contiguous()
+    an = anchors.detach().float().reshape(-1, 4).contiguous()
+    ann = anno.detach().float().contiguous()
+    maxn = ann.shape[1]
+    blocks = call("mpn_focal_blocks", A)
+    part = ops.workspace(B * blocks * 4 * 4, dev, slot=6)
+    per_img = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    call("mpn_focal_forward", ops.ptr(c), ops.ptr(r), ops.ptr(an), ops.ptr(ann), B, A, maxn, ops.ptr(part), ops.ptr(per_img),
+         ops.ptr(out), ops.stream_ptr())
+    return out, (c, r, an, ann, per_img)
+
+
+def focal_backward_raw(saved, gs):
+    """gs: device float[2] = upstream gradients of {cls loss, reg loss}.  Returns (dcls [B,A,1], dreg [B,A,4])."""
+    c, r, an, ann, per_img = saved
+    B, A = c.shape[0], c.shape[1]
+    dev = c.device
+    dcls = torch.empty((B, A, 1), dtype=torch.float32, device=dev)
+    dreg = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
+    call("mpn_focal_backward", ops.ptr(c), ops.ptr(r), ops.ptr(an), ops.ptr(ann), B, A, ann.shape[1], ops.ptr(per_img),
+         ops.ptr(gs), ops.ptr(dcls), ops.ptr(dreg), ops.stream_ptr())
+    return dcls, dreg
+
+
 class _Focal(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cls, reg, anchors, anno):
-        B, A = cls.shape[0], cls.shape[1]
-        if cls.shape[2] != 1:
-            raise NotImplementedError("the hot path is single-class (posenet.py:189 num_classes=1)")
-        dev = cls.device
-        c = cls.detach().float().contiguous()
-        r = reg.detach().float().contiguous()
-        an = anchors.detach().float().reshape(-1, 4).contiguous()
-        ann = anno.detach().float().contiguous()
-        maxn = ann.shape[1]
-        blocks = call("mpn_focal_blocks", A)
-        part = ops.workspace(B * blocks * 4 * 4, dev, slot=6)
-        per_img = torch.empty((B, 4), dtype=torch.float32, device=dev)
-        out = torch.empty(2, dtype=torch.float32, device=dev)
-        call("mpn_focal_forward", ops.ptr(c), ops.ptr(r), ops.ptr(an), ops.ptr(ann), B, A, maxn, ops.ptr(part), ops.ptr(per_img),
-             ops.ptr(out), ops.stream_ptr())
-        ctx.saved = (c, r, an, ann, per_img)
+        out, ctx.saved = focal_forward_raw(cls, reg, anchors, anno)
         return out[0:1].clone(), out[1:2].clone()
 
     @staticmethod
     def backward(ctx, gc, gr):
-        c, r, an, ann, per_img = ctx.saved
-        B, A = c.shape[0], c.shape[1]
-        dev = c.device
-        dcls = torch.empty((B, A, 1), dtype=torch.float32, device=dev)
-        dreg = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
-        gs = torch.empty(2, dtype=torch.float32, device=dev)      # {d/d cls_loss, d/d reg_loss}
+        gs = torch.empty(2, dtype=torch.float32, device=gc.device)      # {d/d cls_loss, d/d reg_loss}
         gs[0:1].copy_(gc.detach().reshape(1))
         gs[1:2].copy_(gr.detach().reshape(1))
-        call("mpn_focal_backward", ops.ptr(c), ops.ptr(r), ops.ptr(an), ops.ptr(ann), B, A, ann.shape[1], ops.ptr(per_img),
-             ops.ptr(gs), ops.ptr(dcls), ops.ptr(dreg), ops.stream_ptr())
+        dcls, dreg = focal_backward_raw(ctx.saved, gs)
         return dcls, dreg, None, None
 
 

@@ -27,7 +27,7 @@ from torch.nn import init
 from .. import ops
 from ..arena import ParamArena
 from ..engine import Ctx, Engine
-from .._lib import MpnError, call
+from .._lib import MpnError, call, gpu_op
 from ..lib.nms.pth_nms import pth_nms
 from . import losses
 from .anchors import Anchors
@@ -278,7 +278,7 @@ class poseNet(nn.Module):
         if ctx.bn_train_ran:
             if all(m.training for m in self._bns) and all(m.num_batches_tracked.data_ptr() == self._nbt[i].data_ptr()
                                                           for i, m in enumerate(self._bns)):
-                self._nbt += 1
+                gpu_op(self._nbt.add_, 1)
             else:
                 for m in self._bns:
                     if m.training:

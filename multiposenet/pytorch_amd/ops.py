@@ -468,6 +468,11 @@ def relu_backward(dz, z, dx=None, accumulate=False):
     return dx
 
 
+def copy_act(dst, src):
+    """dst <- src for two activations of identical storage geometry."""
+    call("mpn_copy_bytes", ptr(dst.t), ptr(src.t), src.t.numel() * src.t.element_size(), stream_ptr())
+
+
 def add_inplace(dst, src):
     call("mpn_add_inplace", ptr(dst.t), ptr(src.t), dst.t.numel(), dtype_code(dst.t.dtype), stream_ptr())
 

@@ -99,7 +99,10 @@ class FusedAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         ar = self.model._arena
         if ar is not None and ar.grad_flat is not None:
-            ar.grad_flat.zero_()
+            if ar.grad_flat.is_cuda:
+                call("mpn_fill_f32", ops.ptr(ar.grad_flat), 0.0, ar.grad_flat.numel(), ops.stream_ptr())
+            else:
+                ar.grad_flat.zero_()
 
     @torch.no_grad()
     def step(self, closure=None):

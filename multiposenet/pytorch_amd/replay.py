@@ -1,0 +1,187 @@
+"""The training step as a recorded launch list.
+
+The eager step costs the host ~16 us per kernel launch (the Python tape of engine.py, ctypes marshalling, torch
+allocations, autograd): ~37 ms for the ~2 300 launches of an R101 step — as long as the GPU needs to run them.  A
+captured hipGraph does not help on this stack (ROCm 7.0 replays a graph node by node from the host: 13 us per node,
+30 us with the weight-gradient branch forked — measured), so the step is recorded one level up instead:
+
+  * ``ReplayedTrainStep`` runs ONE step through an autograd-free copy of the step body (forward tape, loss kernels,
+    gradient zeroing, the reverse tape on both HIP streams, reducer collectives, FusedAdam) while ``_lib.TAPE`` collects
+    every C-ABI launch with its final arguments (device pointers, geometry structs, stream handles) and every
+    stream/event/collective operation as ``(callable, args)``;
+  * the recording runs inside a private ``torch.cuda.MemPool``: activations, gradients and scratch of the step get
+    addresses that no other allocation can take, so the list stays valid; model parameters, optimizer state and the
+    input tensors live outside and are referenced in place;
+  * every later call re-issues the list — a tight loop of ~2 300 foreign calls (~6 us each) — after copying the new
+    batch into the recorded input tensors.
+
+Same interface as ``training.batch_processor.train_step`` / ``graph.GraphedTrainStep``:
+
+    step = ReplayedTrainStep(model, optimizer)
+    loss, saved_for_log = step(inputs, gts)
+
+The result is bit-identical to the eager step (same kernels, same order, same scratch sizes: tests/test_replay_gpu.py).
+Re-recorded when the model moves, the set of trainable parameters / BN modes / compute dtype changes, or a new input
+signature arrives.  'prn_subnet' (host-made dropout seeds) and gradient clipping stay on the eager path.
+"""
+import itertools
+from collections import OrderedDict
+
+import torch
+
+from . import _lib, ops
+from .engine import Ctx
+from .network import losses
+
+_epoch = itertools.count(1 << 20)
+
+
+class _Entry(object):
+    __slots__ = ("tape", "pool", "img", "gts", "logv", "names", "keep", "sig", "loss")
+
+
+class ReplayedTrainStep(object):
+    def __init__(self, model, optimizer, eager_steps=1):
+        self.model = model
+        self.opt = optimizer
+        self.eager_steps = max(1, int(eager_steps))       # steps that fill host-side caches (anchors, transpose table, Adam state)
+        self._entries = {}
+        self._seen = {}
+        self.replays = 0
+
+    # ------------------------------------------------------------------ the autograd-free step body
+    def _body(self, img, subnet, tensors):
+        m = self.model
+        eng = m._engine
+        want_kp = subnet in ("keypoint_subnet", "train_both")
+        want_det = subnet in ("detection_subnet", "train_both")
+        m._prepare(img)
+        ctx = Ctx(True)
+        c2, c3, c4, c5 = eng.backbone(ctx, img)
+        grads = {}
+        kp8 = det2 = None
+        # same operation order as poseNet.keypoint_forward / detection_forward / train_both_forward (the reverse tape, hence the
+        # order in which gradients accumulate into shared feature maps, follows it)
+        kp_feats = eng.kp_pyramid(ctx, c2, c3, c4, c5) if want_kp else None
+        det_feats = eng.det_pyramid(ctx, c3, c4, c5) if want_det else None
+        if want_kp:
+            pred, saved = eng.keypoint_head(ctx, kp_feats, True)
+        if want_det:
+            cls, reg = eng.detection_head(ctx, det_feats)
+        m._finish_forward(ctx)
+        dev = img.device
+        if want_kp:
+            heat = ops.nchw_to_nhwc_f32(tensors[0].detach().float())
+            wgt = ops.nchw_to_nhwc_f32(tensors[1].detach().float())
+            pm = [losses._pixel_major(p) for p in saved + [pred]]
+            kp8 = losses.mse_forward_raw(pm, heat, wgt)
+        if want_det:
+            anno = tensors[2] if want_kp else tensors[0]
+            det2, fsaved = losses.focal_forward_raw(cls, reg, m.anchors(img), anno)
+        logv = torch.zeros(12, dtype=torch.float32, device=dev)
+        _lib.call("mpn_step_log", ops.ptr(kp8), ops.ptr(det2), ops.ptr(logv), ops.stream_ptr())
+        self.opt.zero_grad()
+        ones = self._ones(dev)
+        if want_kp:      # d(total)/d(heat-map total) = 1 (posenet.py:387 sums the level losses; the combined step adds the two totals)
+            for slot, g in zip(("k0", "k1", "k2", "k3", "pred"), losses.mse_backward_raw(pm, heat, wgt, ones, [True] * 5)):
+                grads[slot] = g
+        if want_det:     # d(total)/d(cls loss) = d(total)/d(reg loss) = 1 (posenet.py:417-421)
+            grads["cls"], grads["reg"] = losses.focal_backward_raw(fsaved, ones)
+        eng.run_backward(ctx, grads)
+        self.opt.step()
+        return logv, want_kp, want_det
+
+    def _ones(self, dev):
+        t = getattr(self, "_ones_t", None)
+        if t is None or t.device != dev:
+            t = self._ones_t = torch.ones(2, dtype=torch.float32, device=dev)
+        return t
+
+    @staticmethod
+    def _log_names(want_kp, want_det):
+        names = []
+        if want_kp:
+            kn = losses.build_names()
+            names += [(kn[j * 2], j) for j in range(5)] + [("max_ht", 6), ("min_ht", 7)]
+        if want_det:
+            names += [("total_loss", 8), ("classification_loss", 9), ("regression_loss", 10)]
+        return names
+
+    def _state_sig(self):
+        m = self.model
+        ar = m._arena
+        return (id(ar), id(ar.grad_flat), tuple(p.requires_grad for p in ar.params), tuple(b.training for b in m._bns),
+                m.compute_dtype, id(m._reducer), m._engine.overlap_wgrad, m._engine.fork_every, id(self.opt._m))
+
+    # ------------------------------------------------------------------ call
+    def __call__(self, inputs, gts):
+        (img, subnet), = inputs
+        gts = list(gts)
+        if gts[0] != subnet:
+            raise ValueError("inputs and gts name different subnets (%r vs %r)" % (subnet, gts[0]))
+        tensors = gts[1:]
+        if subnet not in ("keypoint_subnet", "detection_subnet", "train_both"):
+            from .training.batch_processor import train_step
+            return train_step(self.model, self.opt, inputs, gts)
+        ops.check_device(img)
+        key = (subnet, tuple(img.shape), img.dtype, tuple((tuple(t.shape), t.dtype) for t in tensors))
+        ent = self._entries.get(key)
+        if ent is not None and ent.sig != self._state_sig():
+            ent = None
+            self._entries.pop(key)
+        if ent is None:
+            n = self._seen.get(key, 0)
+            self._seen[key] = n + 1
+            if n < self.eager_steps:
+                logv, kp, det = self._body(img, subnet, tensors)          # plain eager execution of the same body
+                return logv[11], self._log(logv, self._log_names(kp, det))
+            ent = self._record(key, img, subnet, tensors)                  # the recording IS this call's step
+            return ent.loss, self._log(ent.logv, ent.names)
+        if ent.img.data_ptr() != img.data_ptr():
+            ent.img.copy_(img, non_blocking=True)
+        for dst, src in zip(ent.gts, tensors):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        self.opt.sync_hyper()
+        for fn, args, is_c in ent.tape:
+            st = fn(*args)
+            if is_c and st:
+                raise _lib.MpnError("%s failed during replay" % getattr(fn, "__name__", fn))
+        self.replays += 1
+        return ent.loss, self._log(ent.logv, ent.names)
+
+    @staticmethod
+    def _log(logv, names):
+        vals = losses._log_values(logv)          # one D2H copy behind the step (floats, or LazyFloat with set_lazy_log)
+        return OrderedDict((k, vals[i]) for k, i in names)
+
+    # ------------------------------------------------------------------ record
+    def _record(self, key, img, subnet, tensors):
+        m = self.model
+        m._arena.ensure_grads()
+        self.opt.sync_hyper()
+        self._ones(img.device)
+        ent = _Entry()
+        ent.img = img if img.is_contiguous() else img.contiguous()      # the tensors of THIS call become the step's inputs
+        ent.gts = list(tensors)
+        epoch = next(_epoch)
+        pool = torch.cuda.MemPool()
+        tape = []
+        was_on = ops.KERNEL_EVENTS.on
+        ops.KERNEL_EVENTS.on = False
+        ops.WS_EPOCH = epoch
+        _lib.TAPE = tape
+        try:
+            with torch.cuda.use_mem_pool(pool):
+                logv, kp, det = self._body(ent.img, subnet, ent.gts)
+        finally:
+            _lib.TAPE = None
+            ops.WS_EPOCH = 0
+            ops.KERNEL_EVENTS.on = was_on
+        ent.tape, ent.pool, ent.logv = tape, pool, logv
+        ent.loss = logv[11]
+        ent.names = self._log_names(kp, det)
+        ent.keep = ops.take_epoch_workspaces(epoch)
+        ent.sig = self._state_sig()
+        self._entries[key] = ent
+        return ent
