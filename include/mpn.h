@@ -54,11 +54,22 @@ typedef struct MpnConvParams {
     int32_t accumulate;   /* y = y + result (act must be 0)                                       */
     int32_t dtype;        /* element type of x, w                                                 */
     int32_t out_f32;      /* 1: y (and res) are f32 even when dtype is bf16                       */
+    /* Pyramid mode (nseg > 0): ONE launch applies the same weights to nseg <= MPN_MAX_SEG feature maps of different sizes —
+     * the shared RetinaNet towers of network/posenet.py:33-117,327-328, which the reference runs level by level.  Level l
+     * has its own dense tensors seg_x[l] / seg_y[l] ([B][seg_H][seg_W][channels], same channel strides x_sW / y_sP as the
+     * single-tensor fields; stride 1, output size = input size) and owns the pixel tiles [seg_tile0[l], seg_tile0[l+1]);
+     * a workgroup never straddles two levels.  x, y, H, W, Ho, Wo, x_sB, x_sH, y_sB are ignored in this mode.           */
+    int32_t nseg;
+    int32_t seg_H[5], seg_W[5];
+    int32_t seg_tile0[6];
+    const void* seg_x[5];
+    void* seg_y[5];
 } MpnConvParams;
+#define MPN_MAX_SEG 5
 
 /* number of pixel tiles (rows of `stats`) mpn_conv_forward will use for this problem */
 int mpn_conv_stats_tiles(const MpnConvParams* p);
-/* output-channel rows of the tile (128 / 64 / 32) the launcher will pick: names the kernel instantiation */
+/* output-channel rows of the tile (256 / 128 / 64 / 32) the launcher will pick: names the kernel instantiation */
 int mpn_conv_tile_rows(const MpnConvParams* p);
 int mpn_conv_forward(const MpnConvParams* p, void* stream);
 
@@ -78,9 +89,22 @@ typedef struct MpnWgradParams {
                            * only by the bf16 LDS-DMA kernel (mpn_conv_wgrad_kernel_id & 1), where it costs one
                            * extra MFMA against a vector of ones per dY fragment; otherwise must be NULL          */
     float* db_ws;         /* workspace, >= chunks * Cout floats, when db != NULL and chunks > 1                    */
+    /* Pyramid mode (nseg > 0, LDS-DMA kernel only): the contraction runs over the pixels of nseg feature maps that share the
+     * weights (see MpnConvParams); level l = dense tensors seg_x[l] / seg_dy[l] of size [B][seg_H][seg_W][.] (stride 1, same
+     * size in and out) and owns the pixel slices [seg_chunk0[l], seg_chunk0[l+1]) of seg_chunk_pixels pixels each.  Fill
+     * chunks / seg_chunk0 / seg_chunk_pixels with mpn_conv_wgrad_seg_plan().                                              */
+    int32_t nseg;
+    int32_t seg_H[5], seg_W[5];
+    int32_t seg_chunk0[6];
+    int32_t seg_chunk_pixels;
+    const void* seg_x[5];
+    const void* seg_dy[5];
 } MpnWgradParams;
 
 int mpn_conv_wgrad_chunks(const MpnWgradParams* p);
+/* pyramid mode: chooses the slice length for the summed pixel count, writes p->chunks, p->seg_chunk0, p->seg_chunk_pixels;
+ * returns the number of slices (or a negative error) */
+int mpn_conv_wgrad_seg_plan(MpnWgradParams* p);
 int mpn_conv_wgrad(const MpnWgradParams* p, void* stream);
 /* first stage only (chunks > 1): the per-slice partial gradients go to ws and the caller finishes with
  * mpn_reduce_partials(ws, chunks, Cout*R*S*Cin, dw, 1, stream) — lets a profiler bracket the MFMA kernel alone */

@@ -35,6 +35,8 @@ class ConvParams(ctypes.Structure):
         ("mode", ctypes.c_int32), ("act", ctypes.c_int32), ("res_mode", ctypes.c_int32),
         ("res_H", ctypes.c_int32), ("res_W", ctypes.c_int32), ("accumulate", ctypes.c_int32),
         ("dtype", ctypes.c_int32), ("out_f32", ctypes.c_int32),
+        ("nseg", ctypes.c_int32), ("seg_H", ctypes.c_int32 * 5), ("seg_W", ctypes.c_int32 * 5), ("seg_tile0", ctypes.c_int32 * 6),
+        ("seg_x", ctypes.c_void_p * 5), ("seg_y", ctypes.c_void_p * 5),
     ]
 
 
@@ -47,6 +49,8 @@ class WgradParams(ctypes.Structure):
         ("R", ctypes.c_int32), ("S", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32),
         ("dtype", ctypes.c_int32), ("chunks", ctypes.c_int32),
         ("db", ctypes.c_void_p), ("db_ws", ctypes.c_void_p),
+        ("nseg", ctypes.c_int32), ("seg_H", ctypes.c_int32 * 5), ("seg_W", ctypes.c_int32 * 5), ("seg_chunk0", ctypes.c_int32 * 6),
+        ("seg_chunk_pixels", ctypes.c_int32), ("seg_x", ctypes.c_void_p * 5), ("seg_dy", ctypes.c_void_p * 5),
     ]
 
 
@@ -66,6 +70,7 @@ SIGNATURES = {
     "mpn_conv_tile_rows": (_i, [_PC]),
     "mpn_conv_forward": (_i, [_PC, _vp]),
     "mpn_conv_wgrad_chunks": (_i, [_PW]),
+    "mpn_conv_wgrad_seg_plan": (_i, [_PW]),
     "mpn_conv_wgrad": (_i, [_PW, _vp]),
     "mpn_conv_wgrad_partials": (_i, [_PW, _vp]),
     "mpn_conv_wgrad_kernel_id": (_i, [_PW]),
@@ -135,7 +140,7 @@ SIGNATURES = {
 }
 
 # entry points that return a count, not a status
-_COUNT_FUNCS = {"mpn_conv_stats_tiles", "mpn_conv_tile_rows", "mpn_conv_wgrad_chunks", "mpn_conv_wgrad_kernel_id", "mpn_bn_bwd_chunks", "mpn_channel_sum_chunks",
+_COUNT_FUNCS = {"mpn_conv_stats_tiles", "mpn_conv_tile_rows", "mpn_conv_wgrad_chunks", "mpn_conv_wgrad_seg_plan", "mpn_conv_wgrad_kernel_id", "mpn_bn_bwd_chunks", "mpn_channel_sum_chunks",
                 "mpn_mse_chunks", "mpn_focal_blocks", "mpn_bce_chunks", "mpn_nms_workspace_bytes", "mpn_nms_batched_workspace_bytes", "mpn_version"}
 
 _lib = None

@@ -324,17 +324,30 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // are invisible to the compiler's waitcnt pass: completion is counted by hand (vmcnt(LPS) = everything but the
 // newest k-step has landed) and the barrier is the raw s_barrier, so the ring never drains inside the loop.
 template <typename T, int TC, int TP, bool OUTF32, bool GENERAL>
-__global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_kernel(const MpnConvParams p, const int dbg) {
+__global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_kernel(const MpnConvParams pk, const int dbg) {
     using C = ConvCfg<T, TC, TP>;
     __shared__ __attribute__((aligned(16))) unsigned char lds[C::NST * C::STAGE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave / C::WAVES_P, wp = wave % C::WAVES_P;
-    const int tilesC = (p.Cout_store + TC - 1) / TC;
+    const int tilesC = (pk.Cout_store + TC - 1) / TC;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int tp = bid / tilesC;
+    const int tc = bid - tp * tilesC;
+    MpnConvParams p = pk;                        // wave-uniform working copy; pyramid mode patches in the level's tensors
+    if (pk.nseg > 0) {
+        int l = 0;
+#pragma unroll
+        for (int k = 1; k < MPN_MAX_SEG; ++k) l += (k < pk.nseg && tp >= pk.seg_tile0[k]) ? 1 : 0;
+        l = __builtin_amdgcn_readfirstlane(l);                  // block-uniform: keep the level's geometry in scalar registers
+        tp -= pk.seg_tile0[l];
+        p.x = pk.seg_x[l]; p.y = pk.seg_y[l];
+        p.H = p.Ho = pk.seg_H[l]; p.W = p.Wo = pk.seg_W[l];
+        p.x_sH = (int64_t)p.W * pk.x_sW; p.x_sB = (int64_t)p.H * p.x_sH;
+        p.y_sB = (int64_t)p.H * p.W * pk.y_sP;
+    }
     const unsigned HoWo = (unsigned)p.Ho * (unsigned)p.Wo;
     const unsigned P = (unsigned)p.B * HoWo;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tp = bid / tilesC, tc = bid - tp * tilesC;
     const long p0 = (long)tp * TP;
     const int c0 = tc * TC;
     constexpr unsigned TS = (unsigned)sizeof(T);
@@ -485,8 +498,8 @@ int launch_conv_k(const MpnConvParams& p, int tc, long grid, int dbg, hipStream_
 
 template <typename T, bool OUTF32>
 int launch_conv(const MpnConvParams& p, hipStream_t st) {
-    const long P = (long)p.B * p.Ho * p.Wo;
-    const long tilesP = (P + kTP - 1) / kTP;
+    const long P = p.nseg > 0 ? (long)p.seg_tile0[p.nseg] * kTP : (long)p.B * p.Ho * p.Wo;
+    const long tilesP = p.nseg > 0 ? (long)p.seg_tile0[p.nseg] : (P + kTP - 1) / kTP;
     const int tc = pick_tc(p, tilesP);
     const long tilesC = (p.Cout_store + tc - 1) / tc;
     const long grid = tilesP * tilesC;
@@ -508,14 +521,24 @@ extern "C" int mpn_conv_stats_tiles(const MpnConvParams* p) {
 extern "C" int mpn_conv_tile_rows(const MpnConvParams* p) {
     if (!p) return MPN_E_BADARG;
     const long P = (long)p->B * p->Ho * p->Wo;
-    return pick_tc(*p, (P + kTP - 1) / kTP);
+    return pick_tc(*p, p->nseg > 0 ? (long)p->seg_tile0[p->nseg] : (P + kTP - 1) / kTP);
 }
 
 extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     if (!pp) return MPN_E_BADARG;
     const MpnConvParams& p = *pp;
-    MPN_CHECK_ARG(p.x && p.w && p.y);
-    MPN_CHECK_ARG(p.B > 0 && p.Ho > 0 && p.Wo > 0 && p.H > 0 && p.W > 0);
+    if (p.nseg > 0) {       // pyramid mode: per-level tensors, shared weights; stride 1, same-size output, no statistics / residual
+        MPN_CHECK_ARG(p.nseg <= MPN_MAX_SEG && p.w && p.B > 0 && p.stride == 1 && !p.stats && p.res_mode == 0 && p.seg_tile0[0] == 0);
+        MPN_CHECK_ARG(2 * p.pad == p.R - 1 && p.R == p.S);
+        for (int l = 0; l < p.nseg; ++l) {
+            MPN_CHECK_ARG(p.seg_x[l] && p.seg_y[l] && p.seg_H[l] > 0 && p.seg_W[l] > 0);
+            const long tiles = ((long)p.B * p.seg_H[l] * p.seg_W[l] + kTP - 1) / kTP;
+            MPN_CHECK_ARG(p.seg_tile0[l + 1] - p.seg_tile0[l] == tiles);
+        }
+    } else {
+        MPN_CHECK_ARG(p.x && p.y && p.Ho > 0 && p.Wo > 0 && p.H > 0 && p.W > 0);
+    }
+    MPN_CHECK_ARG(p.w && p.B > 0);
     MPN_CHECK_ARG(mpn_dtype_ok(p.dtype));
     const int kc = p.dtype == MPN_F32 ? 16 : 32;
     MPN_CHECK_ARG(p.Cin > 0 && p.Cin % kc == 0);
@@ -529,7 +552,9 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     {   // buffer descriptors address at most 4 GB per operand
         const int64_t ts = p.dtype == MPN_F32 ? 4 : 2;
         const int64_t row = (int64_t)p.R * p.S * p.Cin * ts;
-        if ((int64_t)p.B * p.x_sB * ts + row >= 0xfffffff0LL || (int64_t)(p.Cout + 1) * row >= 0xfffffff0LL) return MPN_E_UNSUPPORTED;
+        int64_t xb = (int64_t)p.B * p.x_sB * ts;
+        for (int l = 0; l < p.nseg; ++l) { const int64_t v = (int64_t)p.B * p.seg_H[l] * p.seg_W[l] * p.x_sW * ts; if (l == 0 || v > xb) xb = v; }
+        if (xb + row >= 0xfffffff0LL || (int64_t)(p.Cout + 1) * row >= 0xfffffff0LL) return MPN_E_UNSUPPORTED;
     }          // activation is applied before the residual stage
     hipStream_t st = (hipStream_t)stream;
     if (p.dtype == MPN_F32) return launch_conv<float, false>(p, st);       // OT == T == float

@@ -336,8 +336,16 @@ template <int ROWB> __device__ __forceinline__ int dma_swz(int k) {
     return ROWB >= 256 ? 2 * ((k & 3) | (((k >> 3) & 1) << 2)) : 2 * (((k >> 1) & 1) | (((k >> 3) & 1) << 1));
 }
 
-template <typename T, int TM, int TN>
-__device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& p, long chunk_pixels) {
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ const void* rfl_ptr(const void* q) {
+    const uint64_t a = (uint64_t)q;
+    return (const void*)(((uint64_t)(unsigned)rfl((int)(a >> 32)) << 32) | (unsigned)rfl((int)a));
+}
+
+// SEG = pyramid mode (MpnWgradParams::nseg > 0): a separate instantiation, so the single-tensor kernels keep their register
+// allocation (the level lookup costs ~30 VGPRs of address arithmetic that the compiler no longer proves uniform)
+template <typename T, int TM, int TN, bool SEG>
+__device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, long chunk_pixels) {
     constexpr int KP = 32, NST = 3;
     constexpr int ROWA = TM * 2, ROWB = TN * 2;              // bytes per pixel row of each tile
     constexpr int A_BYTES = KP * ROWA, B_BYTES = KP * ROWB;
@@ -349,17 +357,29 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& p, lon
     __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tilesM = (p.Cin + TM - 1) / TM, tilesN = (p.Cout + TN - 1) / TN;
-    const int taps = p.R * p.S;
+    const int tilesM = (pk.Cin + TM - 1) / TM, tilesN = (pk.Cout + TN - 1) / TN;
+    const int taps = pk.R * pk.S;
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = bid % tilesN; bid /= tilesN;
     const int tm = bid % tilesM; bid /= tilesM;
     const int tap = bid % taps; bid /= taps;
-    const int chunk = bid;
+    const int chunk = bid;                        // global slice index (partial-sum slot)
+    MpnWgradParams p = pk;                        // working copy; pyramid mode patches in the level's tensors
+    int chunk_local = chunk;
+    if (SEG) {
+        int l = 0;
+#pragma unroll
+        for (int k = 1; k < 5; ++k) l += (k < pk.nseg && chunk >= pk.seg_chunk0[k]) ? 1 : 0;
+        l = rfl(l);
+        chunk_local = rfl(chunk - pk.seg_chunk0[l]);
+        p.x = rfl_ptr(pk.seg_x[l]); p.dy = rfl_ptr(pk.seg_dy[l]);
+        p.H = p.Ho = rfl(pk.seg_H[l]); p.W = p.Wo = rfl(pk.seg_W[l]);
+        p.x_sH = (int64_t)p.W * pk.x_sW; p.x_sB = (int64_t)p.H * p.x_sH;
+    }
     const int r = tap / p.S, s = tap - r * p.S;
     const int m0 = tm * TM, n0 = tn * TN;
     const long P = (long)p.B * p.Ho * p.Wo;
-    const long k_begin = (long)chunk * chunk_pixels;
+    const long k_begin = (long)chunk_local * chunk_pixels;
     long k_end = k_begin + chunk_pixels; if (k_end > P) k_end = P;
     const int dy_cs = ((p.Cout + 31) / 32) * 32;
 
@@ -386,7 +406,7 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& p, lon
         const int chan = ((lane % (ROWB / 16)) ^ dma_swz<ROWB>(row)) * 8;
         b_voff[q] = ((n0 + chan) < dy_cs) ? (unsigned)(((k_begin + row) * (long)p.dy_sP + n0 + chan) * 2) : DMA_OOB;
     }
-    const unsigned b_step = (unsigned)(KP * p.dy_sP * 2);
+    const unsigned b_step = (unsigned)__builtin_amdgcn_readfirstlane((int)(KP * p.dy_sP * 2));
     unsigned b_soff = 0;
     const int adv_t = KP / p.Wo, adv_w = KP - adv_t * p.Wo, adv_b = adv_t / p.Ho, adv_h = adv_t - adv_b * p.Ho;
 
@@ -507,11 +527,19 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& p, lon
 
 template <int TM, int TN>
 __global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_kernel(const MpnWgradParams p, long chunk_pixels) {
-    conv_wgrad_dma_body<bf16_t, TM, TN>(p, chunk_pixels);
+    conv_wgrad_dma_body<bf16_t, TM, TN, false>(p, chunk_pixels);
 }
 template <int TM, int TN>
 __global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_f16_kernel(const MpnWgradParams p, long chunk_pixels) {
-    conv_wgrad_dma_body<f16_t, TM, TN>(p, chunk_pixels);
+    conv_wgrad_dma_body<f16_t, TM, TN, false>(p, chunk_pixels);
+}
+template <int TM, int TN>
+__global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_seg_kernel(const MpnWgradParams p, long chunk_pixels) {
+    conv_wgrad_dma_body<bf16_t, TM, TN, true>(p, chunk_pixels);
+}
+template <int TM, int TN>
+__global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_seg_f16_kernel(const MpnWgradParams p, long chunk_pixels) {
+    conv_wgrad_dma_body<f16_t, TM, TN, true>(p, chunk_pixels);
 }
 
 // dst[i] (+)= sum_c ws[c][i], chunks added in index order (deterministic).  (A variant that split the chunks over four
@@ -570,10 +598,25 @@ int launch_wgrad_n(const MpnWgradParams& p, int tn, long grid, long chunk_pixels
 
 // bf16 launches whose tensors fit 32-bit buffer offsets take the LDS-DMA kernel (tiles of 64 or 128 channels; narrower
 // operands ride in a zero-filled 64-wide tile); everything else (f32 parity path, > 2 GB tensors) the generic kernel.
+inline long wgrad_total_pixels(const MpnWgradParams& p) {
+    if (p.nseg <= 0) return (long)p.B * p.Ho * p.Wo;
+    long t = 0;
+    for (int l = 0; l < p.nseg; ++l) t += (long)p.B * p.seg_H[l] * p.seg_W[l];
+    return t;
+}
+
 inline bool wgrad_uses_dma(const MpnWgradParams& p) {
     static const bool use_dma = !(getenv("MPN_WGRAD_NO_DMA") && atoi(getenv("MPN_WGRAD_NO_DMA")));
-    const long P = (long)p.B * p.Ho * p.Wo;
-    const bool small = (long)p.B * p.x_sB * 2 < 0x7fffffffL && P * p.dy_sP * 2 < 0x7fffffffL;
+    long P = (long)p.B * p.Ho * p.Wo, xb = (long)p.B * p.x_sB;
+    if (p.nseg > 0) {
+        P = 0; xb = 0;
+        for (int l = 0; l < p.nseg; ++l) {
+            const long pl = (long)p.B * p.seg_H[l] * p.seg_W[l];
+            if (pl > P) P = pl;
+            if (pl * p.x_sW > xb) xb = pl * p.x_sW;
+        }
+    }
+    const bool small = xb * 2 < 0x7fffffffL && P * p.dy_sP * 2 < 0x7fffffffL;
     return (p.dtype == MPN_BF16 || p.dtype == MPN_F16) && use_dma && small && p.Cin % 8 == 0;
 }
 
@@ -602,10 +645,11 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st, bool reduce = true) {
     int tm, tn;
     wgrad_tiles(p, tm, tn);
     const long tilesM = (p.Cin + tm - 1) / tm, tilesN = (p.Cout + tn - 1) / tn;
-    const long P = (long)p.B * p.Ho * p.Wo;
+    const long P = wgrad_total_pixels(p);
     const int kp = sizeof(T) == 2 ? 32 : 16;
     long chunk_pixels = (P + p.chunks - 1) / p.chunks;
     chunk_pixels = ((chunk_pixels + kp - 1) / kp) * kp;
+    if (p.nseg > 0) chunk_pixels = p.seg_chunk_pixels;
     const long grid = tilesM * tilesN * p.R * p.S * p.chunks;
     if (grid <= 0 || grid > 0x7fffffffL || P >= 0x7fffffffL) return MPN_E_BADARG;
     int rc;
@@ -617,7 +661,10 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st, bool reduce = true) {
         else if (tm == 128) hipLaunchKernelGGL((KERNEL<128, 64>), g, blk, 0, st, p, chunk_pixels);                       \
         else if (tn == 128) hipLaunchKernelGGL((KERNEL<64, 128>), g, blk, 0, st, p, chunk_pixels);                       \
         else hipLaunchKernelGGL((KERNEL<64, 64>), g, blk, 0, st, p, chunk_pixels)
-        if (p.dtype == MPN_F16) { MPN_WGRAD_DMA_LAUNCH(conv_wgrad_dma_f16_kernel); }
+        if (p.nseg > 0) {
+            if (p.dtype == MPN_F16) { MPN_WGRAD_DMA_LAUNCH(conv_wgrad_dma_seg_f16_kernel); }
+            else { MPN_WGRAD_DMA_LAUNCH(conv_wgrad_dma_seg_kernel); }
+        } else if (p.dtype == MPN_F16) { MPN_WGRAD_DMA_LAUNCH(conv_wgrad_dma_f16_kernel); }
         else { MPN_WGRAD_DMA_LAUNCH(conv_wgrad_dma_kernel); }
 #undef MPN_WGRAD_DMA_LAUNCH
         rc = mpn_launch_status();
@@ -639,12 +686,31 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st, bool reduce = true) {
 
 }  // namespace
 
+extern "C" int mpn_conv_wgrad_seg_plan(MpnWgradParams* p) {
+    if (!p || p->nseg <= 0 || p->nseg > 5) return MPN_E_BADARG;
+    const int want = mpn_conv_wgrad_chunks(p);
+    if (want < 1) return want;
+    const long P = wgrad_total_pixels(*p);
+    long cp = (P + want - 1) / want;
+    cp = ((cp + 31) / 32) * 32;
+    int c = 0;
+    for (int l = 0; l < p->nseg; ++l) {
+        p->seg_chunk0[l] = c;
+        const long pl = (long)p->B * p->seg_H[l] * p->seg_W[l];
+        c += (int)((pl + cp - 1) / cp);
+    }
+    p->seg_chunk0[p->nseg] = c;
+    p->seg_chunk_pixels = (int)cp;
+    p->chunks = c;
+    return c;
+}
+
 extern "C" int mpn_conv_wgrad_chunks(const MpnWgradParams* p) {
     if (!p) return MPN_E_BADARG;
     int tm, tn;
     wgrad_tiles(*p, tm, tn);
     const long tiles = (long)((p->Cin + tm - 1) / tm) * ((p->Cout + tn - 1) / tn) * p->R * p->S;
-    const long P = (long)p->B * p->Ho * p->Wo;
+    const long P = wgrad_total_pixels(*p);
     static const long target = getenv("MPN_WGRAD_TARGET") ? atol(getenv("MPN_WGRAD_TARGET")) : kWgradTarget;
     static const long minpix = getenv("MPN_WGRAD_MINPIX") ? atol(getenv("MPN_WGRAD_MINPIX")) : 512;
     long want = (target + tiles - 1) / tiles;          // ~2 workgroups per CU: with the DMA ring long slices run near peak and partial-sum traffic dominates
@@ -658,9 +724,14 @@ extern "C" int mpn_conv_wgrad_chunks(const MpnWgradParams* p) {
 extern "C" int mpn_conv_wgrad(const MpnWgradParams* pp, void* stream) {
     if (!pp) return MPN_E_BADARG;
     const MpnWgradParams& p = *pp;
-    MPN_CHECK_ARG(p.x && p.dy && p.dw);
-    MPN_CHECK_ARG(mpn_dtype_ok(p.dtype));
-    MPN_CHECK_ARG(p.B > 0 && p.Ho > 0 && p.Wo > 0 && p.Cin > 0 && p.Cout > 0);
+    MPN_CHECK_ARG(p.dw && mpn_dtype_ok(p.dtype) && p.B > 0 && p.Cin > 0 && p.Cout > 0);
+    if (p.nseg > 0) {
+        MPN_CHECK_ARG(p.nseg <= 5 && wgrad_uses_dma(p) && p.stride == 1 && p.R == p.S && 2 * p.pad == p.R - 1);
+        MPN_CHECK_ARG(p.seg_chunk_pixels > 0 && p.seg_chunk_pixels % 32 == 0 && p.seg_chunk0[0] == 0 && p.seg_chunk0[p.nseg] == p.chunks);
+        for (int l = 0; l < p.nseg; ++l) MPN_CHECK_ARG(p.seg_x[l] && p.seg_dy[l] && p.seg_H[l] > 0 && p.seg_W[l] > 0);
+    } else {
+        MPN_CHECK_ARG(p.x && p.dy && p.Ho > 0 && p.Wo > 0);
+    }
     MPN_CHECK_ARG(p.Cin % 8 == 0);
     MPN_CHECK_ARG(p.chunks >= 1 && (p.chunks == 1 || p.ws));
     MPN_CHECK_ARG(!p.db || (wgrad_uses_dma(p) && (p.chunks == 1 || p.db_ws)));
@@ -673,9 +744,9 @@ extern "C" int mpn_conv_wgrad(const MpnWgradParams* pp, void* stream) {
 extern "C" int mpn_conv_wgrad_partials(const MpnWgradParams* pp, void* stream) {
     if (!pp) return MPN_E_BADARG;
     const MpnWgradParams& p = *pp;
-    MPN_CHECK_ARG(p.x && p.dy && p.dw && p.ws && p.chunks > 1);
+    MPN_CHECK_ARG(p.dw && p.ws && p.chunks > 1 && (p.nseg > 0 || (p.x && p.dy && p.Ho > 0 && p.Wo > 0)));
     MPN_CHECK_ARG(mpn_dtype_ok(p.dtype));
-    MPN_CHECK_ARG(p.B > 0 && p.Ho > 0 && p.Wo > 0 && p.Cin > 0 && p.Cout > 0 && p.Cin % 8 == 0);
+    MPN_CHECK_ARG(p.B > 0 && p.Cin > 0 && p.Cout > 0 && p.Cin % 8 == 0);
     hipStream_t st = (hipStream_t)stream;
     if (p.dtype == MPN_F32) return launch_wgrad<float>(p, st, false);
     if (p.dtype == MPN_F16) return launch_wgrad<f16_t>(p, st, false);

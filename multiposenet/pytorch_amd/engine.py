@@ -75,6 +75,8 @@ class Engine(object):
         # side-stream work is handed over in groups of `fork_every` layers (one event record / wait per group): a captured
         # hipGraph pays for every cross-stream edge, the eager tape does not care much
         self.fork_every = max(1, int(os.environ.get("MPN_SIDE_FORK_EVERY", "1")))
+        # the RetinaNet towers share their weights over p3..p7: one launch per layer over the whole pyramid instead of one per level
+        self.pyramid_towers = os.environ.get("MPN_PYRAMID_TOWERS", "1") != "0"
 
     def side_stream(self, device):
         """Second HIP stream for weight/bias gradients.  They are off the backward critical path (only the
@@ -265,6 +267,80 @@ class Engine(object):
             g, existed = ctx.gbuf(x)
             wt = self.w_t(ctx, layer)
             ops.conv_forward(dy, wt, I, R, S, stride, pad, mode=1, out_hw=(x.H, x.W), cin=wt.shape[3], out=g, accumulate=existed)
+
+    # ------------------------------------------------------------------ shared-weight convolution over a pyramid
+    def conv_seg(self, ctx, xs, layer, act=0, out_f32=False):
+        """layer(x_l) for every level l in ONE launch (stride-1 same-size convolution; posenet.py:327-328 loops over levels)."""
+        O, I, R, S, stride, pad = _geom(layer)
+        bias = layer.bias
+        ys = ops.conv_forward_seg(xs, self.w_fwd(layer), O, R, S, pad, bias=bias.data if bias is not None else None, act=act, out_f32=out_f32)
+        if ctx.train:
+            need = bool(any(x.needs_grad for x in xs) or layer.weight.requires_grad or (bias is not None and bias.requires_grad))
+            for y in ys:
+                y.needs_grad = need
+            if need:
+                self._note_use(ctx, layer.weight)
+                self._note_use(ctx, bias)
+                if any(x.needs_grad for x in xs):
+                    self.w_t(ctx, layer)
+                ctx.tape.append(lambda: self._conv_seg_bwd(ctx, xs, layer, ys, act))
+        return ys
+
+    def _conv_seg_bwd(self, ctx, xs, layer, ys, act):
+        dys = [ctx.pop_grad(y) for y in ys]
+        O, I, R, S, stride, pad = _geom(layer)
+        bias = layer.bias
+        wg = layer.weight.requires_grad
+        bg = bias is not None and bias.requires_grad
+        if all(d is None for d in dys):
+            if wg:
+                self._grad_done(ctx, layer.weight)
+            if bg:
+                self._grad_done(ctx, bias)
+            return
+        if any(d is None for d in dys):
+            raise ops._lib.MpnError("pyramid convolution: gradient missing for some levels")
+        if act == 1:          # ReLU mask over the whole pyramid in one launch when both sides are single buffers
+            fd, fy = ops.seg_flat(dys), ops.seg_flat(ys)
+            if fd is not None and fy is not None and fd.numel() == fy.numel():
+                out = ops.alloc_seg(ys, ys[0].C, dys[0].t.dtype)
+                call("mpn_relu_backward", ops.ptr(fd), ops.ptr(fy), ops.ptr(out[0].seg[0]), fy.numel(), 0, ops.dtype_code(fy.dtype), ops.stream_ptr())
+                dys = out
+            else:
+                dys = [ops.relu_backward(d, y) for d, y in zip(dys, ys)]
+        ar = self.m._arena
+        if wg or bg:
+            def param_grads():
+                handled, fused = (False, False)
+                if wg:
+                    handled, fused = ops.conv_wgrad_seg(xs, dys, ar.grad_seg(layer.weight), O, R, S, pad, db=ar.grad_seg(bias) if bg else None)
+                for x, d in zip(xs, dys):          # per-level path (exact-fp32 kernels) / separate bias gradient
+                    done = fused
+                    if wg and not handled:
+                        done = ops.conv_wgrad(x, d, ar.grad_seg(layer.weight), O, R, S, 1, pad, db=ar.grad_seg(bias) if bg else None)
+                    if bg and not done:
+                        ops.bias_grad(d, ar.grad_seg(bias), O)
+            self._on_side(ctx, dys[0].t.device, (xs, dys), param_grads)
+            if wg:
+                self._grad_done(ctx, layer.weight)
+            if bg:
+                self._grad_done(ctx, bias)
+        if any(x.needs_grad for x in xs):
+            wt = self.w_t(ctx, layer)
+            grouped = ops.seg_flat(xs) is not None
+            if grouped and ctx.grad_of(xs[0]) is None:
+                gs = ops.alloc_seg(xs, xs[0].C, xs[0].t.dtype)          # gradients of a pyramid group live in one buffer too
+                for x, g in zip(xs, gs):
+                    ctx.set_grad(x, g)
+                existed = [False] * len(xs)
+            else:
+                pairs = [ctx.gbuf(x) for x in xs]
+                gs, existed = [g for g, _ in pairs], [e for _, e in pairs]
+            if all(existed) or not any(existed):
+                ops.conv_forward_seg(dys, wt, I, R, S, pad, mode=1, cin=wt.shape[3], outs=gs, accumulate=existed[0])
+            else:
+                for d, x, g, e in zip(dys, xs, gs, existed):
+                    ops.conv_forward(d, wt, I, R, S, 1, pad, mode=1, out_hw=(x.H, x.W), cin=wt.shape[3], out=g, accumulate=e)
 
     def bn(self, ctx, y, stats, layer, relu, res=None, tag=""):
         train_stats = layer.training
@@ -511,17 +587,30 @@ class Engine(object):
         cls_all = torch.empty((B, A, 1), dtype=torch.float32, device=dev)
         outs = []
         off = 0
-        for f, n in zip(feats, cells):
-            r = f
-            for layer in (m.regressionModel.conv1, m.regressionModel.conv2, m.regressionModel.conv3, m.regressionModel.conv4):
-                r, _ = self.conv(ctx, r, layer, act=1)
-            ro, _ = self.conv(ctx, r, m.regressionModel.output, out_f32=True)
-            c = f
-            for layer in (m.classificationModel.conv1, m.classificationModel.conv2, m.classificationModel.conv3, m.classificationModel.conv4):
-                c, _ = self.conv(ctx, c, layer, act=1)
-            co, _ = self.conv(ctx, c, m.classificationModel.output, out_f32=True)
-            outs.append((ro, co, off, n))
-            off += n * 9
+        rm, cm = m.regressionModel, m.classificationModel
+        if self.pyramid_towers and len(feats) > 1:
+            r = c = feats
+            for layer in (rm.conv1, rm.conv2, rm.conv3, rm.conv4):
+                r = self.conv_seg(ctx, r, layer, act=1)
+            ros = self.conv_seg(ctx, r, rm.output, out_f32=True)
+            for layer in (cm.conv1, cm.conv2, cm.conv3, cm.conv4):
+                c = self.conv_seg(ctx, c, layer, act=1)
+            cos = self.conv_seg(ctx, c, cm.output, out_f32=True)
+            for ro, co, n in zip(ros, cos, cells):
+                outs.append((ro, co, off, n))
+                off += n * 9
+        else:
+            for f, n in zip(feats, cells):
+                r = f
+                for layer in (rm.conv1, rm.conv2, rm.conv3, rm.conv4):
+                    r, _ = self.conv(ctx, r, layer, act=1)
+                ro, _ = self.conv(ctx, r, rm.output, out_f32=True)
+                c = f
+                for layer in (cm.conv1, cm.conv2, cm.conv3, cm.conv4):
+                    c, _ = self.conv(ctx, c, layer, act=1)
+                co, _ = self.conv(ctx, c, cm.output, out_f32=True)
+                outs.append((ro, co, off, n))
+                off += n * 9
         # pack the per-level outputs, then one sigmoid over [B,A,1] (its backward needs only p)
         for ro, co, o, n in outs:
             call("mpn_det_pack", ops.ptr(ro.t), 0, ctypes.c_void_p(reg_all.data_ptr() + o * 4 * 4), B, n, ro.Cs, 36, A * 4, ops.stream_ptr())
@@ -537,17 +626,18 @@ class Engine(object):
                         call("mpn_sigmoid_backward", ops.ptr(gc), ops.ptr(cls_all), ops.ptr(dlogit), cls_all.numel(), ops.stream_ptr())
                     if gr is not None:
                         gr = gr.contiguous()
-                    for ro, co, o, n in outs:
+                    # output gradients of all levels in one buffer per tower (the pyramid backward consumes them in one launch)
+                    dros = ops.alloc_seg([x[0] for x in outs], 36, self.cdt)
+                    dcos = ops.alloc_seg([x[1] for x in outs], 9, self.cdt)
+                    for (ro, co, o, n), dr, dc in zip(outs, dros, dcos):
                         if gr is not None and ro.needs_grad:
-                            d = Act(torch.empty(ro.t.shape, dtype=self.cdt, device=dev), 36)
-                            call("mpn_det_unpack", ctypes.c_void_p(gr.data_ptr() + o * 4 * 4), ops.ptr(d.t), ops.dtype_code(self.cdt),
-                                 B, n, d.Cs, 36, A * 4, ops.stream_ptr())
-                            ctx.set_grad(ro, d)
+                            call("mpn_det_unpack", ctypes.c_void_p(gr.data_ptr() + o * 4 * 4), ops.ptr(dr.t), ops.dtype_code(self.cdt),
+                                 B, n, dr.Cs, 36, A * 4, ops.stream_ptr())
+                            ctx.set_grad(ro, dr)
                         if gc is not None and co.needs_grad:
-                            d = Act(torch.empty(co.t.shape, dtype=self.cdt, device=dev), 9)
-                            call("mpn_det_unpack", ctypes.c_void_p(dlogit.data_ptr() + o * 4), ops.ptr(d.t), ops.dtype_code(self.cdt),
-                                 B, n, d.Cs, 9, A, ops.stream_ptr())
-                            ctx.set_grad(co, d)
+                            call("mpn_det_unpack", ctypes.c_void_p(dlogit.data_ptr() + o * 4), ops.ptr(dc.t), ops.dtype_code(self.cdt),
+                                 B, n, dc.Cs, 9, A, ops.stream_ptr())
+                            ctx.set_grad(co, dc)
                 ctx.tape.append(bwd)
         return cls_all, reg_all
 

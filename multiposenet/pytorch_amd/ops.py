@@ -84,7 +84,7 @@ class Act(object):
 
     Cs (channel storage) is a multiple of 32; lanes [C, Cs) hold zeros (see include/mpn.h).
     """
-    __slots__ = ("t", "B", "H", "W", "C", "Cs", "needs_grad", "tag")
+    __slots__ = ("t", "B", "H", "W", "C", "Cs", "needs_grad", "tag", "seg")
 
     def __init__(self, t, C, needs_grad=False, tag=""):
         self.t = t
@@ -92,6 +92,7 @@ class Act(object):
         self.C = C
         self.needs_grad = needs_grad
         self.tag = tag
+        self.seg = None          # (flat buffer, index) when this activation is one level of a pyramid group (alloc_seg)
 
     @staticmethod
     def empty(B, H, W, C, dtype, device, needs_grad=False, tag=""):
@@ -175,6 +176,118 @@ def workspace(nbytes, device, slot=0):
             buf.record_stream(so)
         _ws[key] = buf
     return buf
+
+
+def alloc_seg(like, C, dtype):
+    """One buffer holding an activation per pyramid level (geometry of the Acts in `like`, C channels): the levels are views
+    of a single flat tensor, so element-wise kernels can treat the whole pyramid as one array."""
+    Cs = round_up(C, 32)
+    sizes = [a.B * a.H * a.W * Cs for a in like]
+    flat = torch.empty(sum(sizes), dtype=dtype, device=like[0].t.device)
+    out, off = [], 0
+    for i, (a, n) in enumerate(zip(like, sizes)):
+        v = Act(flat[off: off + n].view(a.B, a.H, a.W, Cs), C)
+        v.seg = (flat, i)
+        out.append(v)
+        off += n
+    return out
+
+
+def seg_flat(acts):
+    """The flat tensor behind a complete pyramid group (None if `acts` is not exactly one group in order)."""
+    if not acts or acts[0].seg is None:
+        return None
+    flat = acts[0].seg[0]
+    for i, a in enumerate(acts):
+        if a.seg is None or a.seg[0] is not flat or a.seg[1] != i:
+            return None
+    return flat if sum(a.t.numel() for a in acts) == flat.numel() else None
+
+
+def conv_forward_seg(xs, w, Cout, R, S, pad, bias=None, act=0, out_f32=False, mode=0, outs=None, accumulate=False, cin=None):
+    """The same convolution (stride 1, same-size output) over every level of a pyramid in ONE launch — the shared RetinaNet
+    towers of posenet.py:327-328.  xs: Acts with equal B / C / dtype.  Returns the per-level outputs (views of one buffer)."""
+    x0 = xs[0]
+    dt = x0.t.dtype
+    odt = torch.float32 if out_f32 else dt
+    if outs is None:
+        outs = alloc_seg(xs, Cout, odt)
+    p = ConvParams()
+    p.w = w.data_ptr()
+    p.bias = bias.data_ptr() if bias is not None else None
+    p.B = x0.B
+    p.Cin = cin if cin is not None else round_up(x0.C, 32 if is16(dt) else 16)
+    p.Cout, p.Cout_store = Cout, outs[0].Cs
+    p.x_sW, p.y_sP = x0.Cs, outs[0].Cs
+    p.R, p.S, p.stride, p.pad = R, S, 1, pad
+    p.mode, p.act, p.accumulate = mode, act, 1 if accumulate else 0
+    p.dtype = dtype_code(dt)
+    p.out_f32 = 1 if (out_f32 and dt != torch.float32) else 0
+    p.nseg = len(xs)
+    tile0 = 0
+    for l, (x, o) in enumerate(zip(xs, outs)):
+        assert (x.B, x.Cs, x.t.dtype) == (x0.B, x0.Cs, dt) and (o.H, o.W, o.Cs, o.t.dtype) == (x.H, x.W, outs[0].Cs, odt)
+        p.seg_x[l], p.seg_y[l] = x.t.data_ptr(), o.t.data_ptr()
+        p.seg_H[l], p.seg_W[l] = x.H, x.W
+        p.seg_tile0[l] = tile0
+        tile0 += (x.B * x.H * x.W + 127) // 128
+    p.seg_tile0[len(xs)] = tile0
+    if KERNEL_EVENTS.on:
+        e0 = KERNEL_EVENTS.begin()
+        call("mpn_conv_forward", ctypes.byref(p), stream_ptr())
+        tc = call("mpn_conv_tile_rows", ctypes.byref(p))
+        general = (bias is not None or accumulate or act != 0 or Cout % tc != 0)
+        name = "conv_igemm_kernel<%s, %d, 128, %s, %s>" % (dtype_name(dt), tc, "true" if p.out_f32 else "false", "true" if general else "false")
+        if KERNEL_EVENTS.detail:
+            name = "%s %dx%d %d->%d pyramid(%s)|0" % ("dgrad" if mode == 1 else "fwd", R, S, p.Cin, Cout, ",".join(str(x.H) for x in xs))
+        KERNEL_EVENTS.end(name, sum(2.0 * x.B * x.H * x.W * Cout * R * S * min(p.Cin, x.C) for x in xs), e0)
+    else:
+        call("mpn_conv_forward", ctypes.byref(p), stream_ptr())
+    return outs
+
+
+def conv_wgrad_seg(xs, dys, dw, Cout, R, S, pad, db=None):
+    """dw += sum over the pyramid levels of wgrad(x_l, dy_l) in ONE launch (LDS-DMA kernel).  Returns (handled, fused_db)."""
+    x0 = xs[0]
+    dev, dt = x0.t.device, x0.t.dtype
+    p = WgradParams()
+    p.dw = dw.data_ptr()
+    p.x_sW, p.dy_sP = x0.Cs, dys[0].Cs
+    p.B, p.Cin, p.Cout = x0.B, x0.C, Cout
+    p.R, p.S, p.stride, p.pad = R, S, 1, pad
+    p.dtype = dtype_code(dt)
+    p.nseg = len(xs)
+    for l, (x, d) in enumerate(zip(xs, dys)):
+        p.seg_x[l], p.seg_dy[l] = x.t.data_ptr(), d.t.data_ptr()
+        p.seg_H[l], p.seg_W[l] = x.H, x.W
+    p.chunks = 1
+    if not (call("mpn_conv_wgrad_kernel_id", ctypes.byref(p)) & 1):
+        return False, False
+    chunks = call("mpn_conv_wgrad_seg_plan", ctypes.byref(p))
+    if chunks < 1:
+        raise _lib.MpnError("mpn_conv_wgrad_seg_plan failed with status %d" % chunks)
+    if chunks > 1:
+        p.ws = workspace(chunks * Cout * R * S * x0.C * 4, dev, slot=1).data_ptr()
+    fused_db = db is not None
+    if fused_db:
+        p.db = db.data_ptr()
+        if chunks > 1:
+            p.db_ws = workspace(chunks * Cout * 4, dev, slot=4).data_ptr()
+    if KERNEL_EVENTS.on:
+        kid = call("mpn_conv_wgrad_kernel_id", ctypes.byref(p))
+        e0 = KERNEL_EVENTS.begin()
+        call("mpn_conv_wgrad_partials" if chunks > 1 else "mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
+        name = "conv_wgrad_dma_seg%s_kernel<%d, %d>" % ("_f16" if dt == torch.float16 else "", kid >> 16, (kid >> 4) & 0xfff)
+        if KERNEL_EVENTS.detail:
+            name = "wgrad %dx%d %d->%d pyramid(%s) chunks=%d|0" % (R, S, x0.C, Cout, ",".join(str(x.H) for x in xs), chunks)
+        KERNEL_EVENTS.end(name, sum(2.0 * x.B * x.H * x.W * Cout * R * S * x.C for x in xs), e0)
+        if chunks > 1:
+            call("mpn_reduce_partials", p.ws, chunks, Cout * R * S * x0.C, p.dw, 1, stream_ptr())
+            if fused_db:
+                call("mpn_reduce_partials", p.db_ws, chunks, Cout, p.db, 1, stream_ptr())
+    else:
+        call("mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
+    return True, fused_db
 
 
 def conv_out_hw(H, W, R, S, stride, pad):

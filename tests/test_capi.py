@@ -42,7 +42,7 @@ def test_struct_layouts_match_header(tmp_path):
     def fields(struct):
         body = src[src.index("typedef struct %s" % struct): src.index("} %s;" % struct)]
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-        return re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*(?:,|;)", body)
+        return re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[\d+\])?\s*(?:,|;)", body)      # scalars and fixed arrays
 
     prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "mpn.h"', 'int main(void){']
     for st, cls in (("MpnConvParams", ConvParams), ("MpnWgradParams", WgradParams)):

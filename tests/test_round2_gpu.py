@@ -357,3 +357,34 @@ def test_two_rank_data_parallel_equals_global_batch_on_device():
            % (str(res[0]["backend"]), rel, len(res[0]["buckets"])))
     assert rel <= 1e-4
     assert abs(float(res[0]["loss_mean"]) - float(res[0]["global_loss"])) <= 1e-5 * abs(float(res[0]["global_loss"]))
+
+
+# ------------------------------------------------------------------------------------------------ pyramid towers
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_pyramid_towers_equal_the_per_level_launches(dtype):
+    """The RetinaNet towers share weights over p3..p7 (posenet.py:327-328): running each layer ONCE over the whole pyramid
+    (MpnConvParams.nseg) gives bit-identical outputs (same k-order per output element whatever the tile) and the same
+    gradients up to the summation order of the split weight-gradient reduction."""
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    m, inputs, gts = _train_setup(50, dtype, 2, 160, seed=140)
+    res = []
+    for pyramid in (False, True):
+        m._engine.pyramid_towers = pyramid
+        m._arena.ensure_grads()
+        m._arena.grad_flat.zero_()
+        pred, (ks, ds) = m(*inputs)
+        loss, log = poseNet.build_loss((ks, ds), *gts)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((ds[0].detach().clone(), ds[1].detach().clone(), loss.detach().clone(), m._arena.grad_flat.clone()))
+    m._engine.pyramid_towers = True
+    (c0, r0, l0, g0), (c1, r1, l1, g1) = res
+    assert torch.equal(c0, c1) and torch.equal(r0, r1) and torch.equal(l0, l1)
+    rel = float((g0 - g1).norm() / g0.norm())
+    report("pyramid towers (%s): outputs and loss bit-identical to per-level launches, gradient arena rel-L2 %.2e" % (str(dtype), rel))
+    assert rel <= (1e-6 if dtype == torch.float32 else 2e-3)
+    # the tower weights themselves: every level contributed
+    w = m.regressionModel.conv2.weight
+    i = m._arena.index[id(w)]
+    seg = slice(m._arena.offsets[i], m._arena.offsets[i] + m._arena.sizes[i])
+    assert float((g0[seg] - g1[seg]).norm() / g0[seg].norm()) <= (1e-6 if dtype == torch.float32 else 2e-3)
