@@ -64,6 +64,21 @@ typedef struct MpnConvParams {
     int32_t seg_tile0[6];
     const void* seg_x[5];
     void* seg_y[5];
+    /* BatchNorm-backward statistics in the epilogue (bnb_partial != NULL; dgrad launches): the tensor this launch completes
+     * is dz, the gradient w.r.t. the OUTPUT of a BatchNorm(+ReLU) layer z = act(bn(y_bn) [+ residual]) (network/fpn.py:28-34).
+     * With g = dz * (z > 0) the launch also writes, per pixel tile, (sum g, sum g * xhat), xhat = (y_bn - mean) * invstd —
+     * exactly what mpn_bn_bwd_reduce would produce in an extra pass over dz, y_bn (and z): bnb_partial [tiles][Cout][2] with
+     * tiles = mpn_conv_stats_tiles(), consumed by mpn_bn_bwd_finalize(partial, tiles, ...).  bnb_y / bnb_z have the geometry,
+     * element type and strides of y; bnb_z == NULL with bnb_relu: the mask is recomputed as y_bn*bnb_scale + bnb_shift > 0 (valid
+     * when the forward had no residual input).  Statistics use the values as stored (after rounding to the element type).    */
+    const void* bnb_y;
+    const void* bnb_z;
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    const float* bnb_scale;
+    const float* bnb_shift;
+    float* bnb_partial;
+    int32_t bnb_relu;
 } MpnConvParams;
 #define MPN_MAX_SEG 5
 

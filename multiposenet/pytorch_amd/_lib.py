@@ -37,6 +37,8 @@ class ConvParams(ctypes.Structure):
         ("dtype", ctypes.c_int32), ("out_f32", ctypes.c_int32),
         ("nseg", ctypes.c_int32), ("seg_H", ctypes.c_int32 * 5), ("seg_W", ctypes.c_int32 * 5), ("seg_tile0", ctypes.c_int32 * 6),
         ("seg_x", ctypes.c_void_p * 5), ("seg_y", ctypes.c_void_p * 5),
+        ("bnb_y", ctypes.c_void_p), ("bnb_z", ctypes.c_void_p), ("bnb_mean", ctypes.c_void_p), ("bnb_invstd", ctypes.c_void_p),
+        ("bnb_scale", ctypes.c_void_p), ("bnb_shift", ctypes.c_void_p), ("bnb_partial", ctypes.c_void_p), ("bnb_relu", ctypes.c_int32),
     ]
 
 

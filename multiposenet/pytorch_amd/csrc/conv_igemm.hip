@@ -238,6 +238,24 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
     unsigned char* stage = lds + (threadIdx.x >> 6) * REGION;
     const int sp = lane / LPP, sc_ = lane % LPP;               // store phase: pixel slot, 16-byte chunk
     const int ccol = c0 + wc * C::WTC + sc_ * EV;              // first channel of this lane's chunk
+    // BatchNorm-backward statistics of the tensor being completed (mpn.h: bnb_*): per-lane sums over the lane's pixels of
+    // its EV channels, reduced over the tile after the store loop
+    const bool bnb = GENERAL && p.bnb_partial != nullptr;
+    const OT* __restrict__ Ybn = (const OT*)p.bnb_y;
+    const OT* __restrict__ Zbn = (const OT*)p.bnb_z;
+    float bs1[EV], bs2[EV], bmu[EV], bis[EV], bsc[EV], bsf[EV];
+    if (bnb) {
+#pragma unroll
+        for (int e = 0; e < EV; ++e) {
+            const int c = ccol + e;
+            const bool live = c < p.Cout;
+            bs1[e] = 0.f; bs2[e] = 0.f;
+            bmu[e] = live ? p.bnb_mean[c] : 0.f;
+            bis[e] = live ? p.bnb_invstd[c] : 0.f;
+            bsc[e] = (live && p.bnb_scale) ? p.bnb_scale[c] : 0.f;
+            bsf[e] = (live && p.bnb_shift) ? p.bnb_shift[c] : 0.f;
+        }
+    }
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
@@ -283,11 +301,58 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                     a.store(reinterpret_cast<OT*>(&v));
                 }
                 *reinterpret_cast<u32x4_t*>(dst) = v;
+                if (bnb) {
+                    const long off = (long)b * p.y_sB + (long)rem * p.y_sP + ccol;
+                    Vec16<OT> dzv, yy, zz;
+                    dzv.load(reinterpret_cast<const OT*>(&v));                  // the value as stored
+                    yy.load(Ybn + off);
+                    if (Zbn) zz.load(Zbn + off);
+#pragma unroll
+                    for (int e = 0; e < EV; ++e) {
+                        float g = dzv.v[e];
+                        if (p.bnb_relu) {
+                            const float zv = Zbn ? zz.v[e] : yy.v[e] * bsc[e] + bsf[e];
+                            if (!(zv > 0.f)) g = 0.f;
+                        }
+                        bs1[e] += g;
+                        bs2[e] += g * ((yy.v[e] - bmu[e]) * bis[e]);
+                    }
+                }
             }
             pix += PPI; rem += PPI;
             while (rem >= HoWo) { rem -= HoWo; ++b; }
         }
         if (ps + 1 < NPASS) __syncthreads();
+    }
+    if (bnb) {
+        // lanes sharing a channel chunk (same sc_, different pixel slot sp): butterfly over the sp bits
+#pragma unroll
+        for (int e = 0; e < EV; ++e) {
+#pragma unroll
+            for (int m = LPP; m < 64; m <<= 1) {
+                bs1[e] += __shfl_xor(bs1[e], m, 64);
+                bs2[e] += __shfl_xor(bs2[e], m, 64);
+            }
+        }
+        __syncthreads();                                        // staging area no longer read
+        if (sp == 0) {
+#pragma unroll
+            for (int e = 0; e < EV; ++e) {
+                const int row = wc * C::WTC + sc_ * EV + e;      // 0..TC-1
+                *reinterpret_cast<float2*>(lds_f + (wp * TC + row) * 2) = make_float2(bs1[e], bs2[e]);
+            }
+        }
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < TC && c0 + t < p.Cout) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < C::WAVES_P; ++w) {
+                a1 += lds_f[(w * TC + t) * 2 + 0];
+                a2 += lds_f[(w * TC + t) * 2 + 1];
+            }
+            *reinterpret_cast<float2*>(p.bnb_partial + ((long)tp * p.Cout + c0 + t) * 2) = make_float2(a1, a2);
+        }
     }
 }
 
@@ -506,7 +571,7 @@ int launch_conv(const MpnConvParams& p, hipStream_t st) {
     if (grid <= 0 || grid > 0x7fffffffL || P >= 0x7fffffffL) return MPN_E_BADARG;
     static const int dbg = getenv("MPN_DEBUG_FLAGS") ? atoi(getenv("MPN_DEBUG_FLAGS")) : 0;   // microbenchmark ablations only
     // "plain" = conv (+ BN tile statistics): no per-element epilogue math at all, lighter register footprint
-    const bool general = p.scale || p.bias || p.res_mode || p.accumulate || p.act || (p.Cout % tc) != 0;
+    const bool general = p.scale || p.bias || p.res_mode || p.accumulate || p.act || (p.Cout % tc) != 0 || p.bnb_partial;
     return general ? launch_conv_k<T, OUTF32, true>(p, tc, grid, dbg, st) : launch_conv_k<T, OUTF32, false>(p, tc, grid, dbg, st);
 }
 
@@ -549,6 +614,8 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     MPN_CHECK_ARG(p.res_mode == 0 || p.res != nullptr);
     MPN_CHECK_ARG(!(p.stats && (p.bias || p.scale || p.res_mode || p.accumulate || p.act)));
     MPN_CHECK_ARG(!((p.res_mode || p.accumulate) && p.act));
+    MPN_CHECK_ARG(!p.bnb_partial || (p.bnb_y && p.bnb_mean && p.bnb_invstd && !p.out_f32 && !p.nseg && !p.stats && !p.act &&
+                                     (!p.bnb_relu || p.bnb_z || (p.bnb_scale && p.bnb_shift))));
     {   // buffer descriptors address at most 4 GB per operand
         const int64_t ts = p.dtype == MPN_F32 ? 4 : 2;
         const int64_t row = (int64_t)p.R * p.S * p.Cin * ts;

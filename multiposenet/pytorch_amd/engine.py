@@ -35,6 +35,8 @@ class Ctx(object):
         self.bn_train_ran = False
         self.side_keep = []      # operands of side-stream launches, kept alive until the streams join
         self.side_pending = []   # closures waiting for the next fork point (Engine.fork_every > 1)
+        self.wt_ready = None     # event: the transposed weight copies (made on the side stream) are complete
+        self.bnb = {}            # id(BN output Act) -> per-tile backward statistics produced by the launch that completed its gradient
 
     def gbuf(self, act, dtype=None):
         """Gradient buffer for ``act``: returns (Act, existed)."""
@@ -77,6 +79,8 @@ class Engine(object):
         self.fork_every = max(1, int(os.environ.get("MPN_SIDE_FORK_EVERY", "1")))
         # the RetinaNet towers share their weights over p3..p7: one launch per layer over the whole pyramid instead of one per level
         self.pyramid_towers = os.environ.get("MPN_PYRAMID_TOWERS", "1") != "0"
+        # BatchNorm-backward statistics ride in the epilogue of the dgrad launch that completes dz (no separate reduction pass)
+        self.fuse_bn_stats = os.environ.get("MPN_BN_FUSED_STATS", "1") != "0"
 
     def side_stream(self, device):
         """Second HIP stream for weight/bias gradients.  They are off the backward critical path (only the
@@ -187,9 +191,30 @@ class Engine(object):
             ctx.wt[key] = wt
             return wt
         if ctx.wt_buf is None:
-            ctx.wt_buf = torch.empty(plan["total"], dtype=self.cdt, device=plan["table"].device)
-            call("mpn_weight_transpose_batched", ops.ptr(self.m._arena.flat), ops.ptr(ctx.wt_buf), ops.ptr(plan["table"]),
-                 plan["n"], plan["blocks"], ops.dtype_code(self.cdt), ops.stream_ptr())
+            dev = plan["table"].device
+            ctx.wt_buf = torch.empty(plan["total"], dtype=self.cdt, device=dev)
+            side = self.side_stream(dev)
+            if side is not None:
+                ctx.wt_buf.record_stream(side)
+
+            def transpose_all():
+                call("mpn_weight_transpose_batched", ops.ptr(self.m._arena.flat), ops.ptr(ctx.wt_buf), ops.ptr(plan["table"]),
+                     plan["n"], plan["blocks"], ops.dtype_code(self.cdt), ops.stream_ptr())
+            if side is None:
+                transpose_all()
+            else:
+                # only backward reads these copies: make them beside the forward pass (they depend on nothing but the last
+                # optimizer step, which the fork below orders) and let run_backward wait for the event
+                ev = torch.cuda.Event()
+                gpu_op(ev.record, torch.cuda.current_stream(dev))
+                gpu_op(side.wait_event, ev)
+                ops.push_stream(side)
+                try:
+                    transpose_all()
+                finally:
+                    ops.pop_stream()
+                ctx.wt_ready = torch.cuda.Event()
+                gpu_op(ctx.wt_ready.record, side)
         off, shape = plan["views"][key]
         n = shape[0] * shape[1] * shape[2] * shape[3]
         wt = ctx.wt_buf[off: off + n].view(shape)
@@ -220,6 +245,9 @@ class Engine(object):
                 self._note_use(ctx, bias)
                 if x.needs_grad:
                     self.w_t(ctx, layer)       # make the transposed operand now (weights may change before backward)
+                    x.cons += 1
+                if res is not None and res.needs_grad:
+                    res.cons += 1
                 ctx.tape.append(lambda: self._conv_bwd(ctx, x, layer, y, act, res, res_mode))
         return y, st
 
@@ -232,6 +260,10 @@ class Engine(object):
                 self._grad_done(ctx, layer.weight)
             if bias is not None and bias.requires_grad:
                 self._grad_done(ctx, bias)
+            if x.needs_grad:
+                x.cons -= 1
+            if res is not None and res.needs_grad:
+                res.cons -= 1
             return
         if dy.t.dtype != self.cdt:
             raise ops._lib.MpnError("gradient dtype mismatch for %s" % y.tag)
@@ -240,6 +272,7 @@ class Engine(object):
         elif act == 2:
             raise ops._lib.MpnError("sigmoid backward is handled at the detection edge")
         if res is not None and res.needs_grad:
+            res.cons -= 1
             g, existed = ctx.gbuf(res)
             if res_mode == 2:
                 ops.upsample_backward(dy, g, existed)
@@ -264,9 +297,18 @@ class Engine(object):
             if bg:
                 self._grad_done(ctx, bias)
         if x.needs_grad:
+            x.cons -= 1
             g, existed = ctx.gbuf(x)
             wt = self.w_t(ctx, layer)
-            ops.conv_forward(dy, wt, I, R, S, stride, pad, mode=1, out_hw=(x.H, x.W), cin=wt.shape[3], out=g, accumulate=existed)
+            bnb = None
+            if x.cons == 0 and x.bn_src is not None and self.fuse_bn_stats:
+                # this launch completes dz of the BatchNorm that produced x: its backward statistics ride in the epilogue
+                by, st, relu, has_res, wants_stats = x.bn_src
+                if wants_stats and by.t.dtype == g.t.dtype:
+                    bnb = (by, x if (relu and has_res) else None, st, relu)
+            _, part = ops.conv_forward(dy, wt, I, R, S, stride, pad, mode=1, out_hw=(x.H, x.W), cin=wt.shape[3], out=g, accumulate=existed, bnb=bnb)
+            if bnb is not None:
+                ctx.bnb[id(x)] = part
 
     # ------------------------------------------------------------------ shared-weight convolution over a pyramid
     def conv_seg(self, ctx, xs, layer, act=0, out_f32=False):
@@ -357,6 +399,10 @@ class Engine(object):
             if z.needs_grad:
                 self._note_use(ctx, layer.weight)
                 self._note_use(ctx, layer.bias)
+                if res is not None and res.needs_grad:
+                    res.cons += 1
+                wants_stats = bool(train_stats or layer.weight.requires_grad or layer.bias.requires_grad)
+                z.bn_src = (y, st, relu, res is not None, wants_stats)
                 ctx.tape.append(lambda: self._bn_bwd(ctx, y, z, st, layer, relu, res, train_stats))
         return z
 
@@ -368,16 +414,20 @@ class Engine(object):
                 self._grad_done(ctx, layer.weight)
             if bg:
                 self._grad_done(ctx, layer.bias)
+            if res is not None and res.needs_grad:
+                res.cons -= 1
             return
         ar = self.m._arena
         dres, dres_acc = None, False
         if res is not None and res.needs_grad:
+            res.cons -= 1
             dres, dres_acc = ctx.gbuf(res)
         want_dy = y.needs_grad
         dy = ops.bn_backward(dz, z, y, st, layer.weight.data, relu, train_stats,
                              dgamma=ar.grad_seg(layer.weight) if wg else None,
                              dbeta=ar.grad_seg(layer.bias) if bg else None,
-                             want_dy=want_dy, dres=dres, dres_acc=dres_acc, remask=bool(relu and res is None))
+                             want_dy=want_dy, dres=dres, dres_acc=dres_acc, remask=bool(relu and res is None),
+                             partial=ctx.bnb.pop(id(z), None))
         if wg:
             self._grad_done(ctx, layer.weight)
         if bg:
@@ -408,8 +458,10 @@ class Engine(object):
         z = ops.relu_forward(x)
         if ctx.train and x.needs_grad:
             z.needs_grad = True
+            x.cons += 1
 
             def bwd():
+                x.cons -= 1
                 dz = ctx.pop_grad(z)
                 if dz is None:
                     return
@@ -422,7 +474,10 @@ class Engine(object):
         need = ctx.train and x.needs_grad
         y, idx = ops.maxpool_forward(x, needs_grad=need)
         if need:
+            x.cons += 1
+
             def bwd():
+                x.cons -= 1
                 dy = ctx.pop_grad(y)
                 if dy is None:
                     return
@@ -653,6 +708,9 @@ class Engine(object):
             m._reducer.launch_stream = side
             m._reducer.pre_launch = (lambda: self.flush_side(ctx, dev)) if side is not None else None
             gpu_op(m._reducer.begin)
+        if ctx.wt_ready is not None:
+            gpu_op(torch.cuda.current_stream(dev).wait_event, ctx.wt_ready)
+            ctx.wt_ready = None
         tape = ctx.tape
         while tape:
             tape.pop()()

@@ -84,7 +84,7 @@ class Act(object):
 
     Cs (channel storage) is a multiple of 32; lanes [C, Cs) hold zeros (see include/mpn.h).
     """
-    __slots__ = ("t", "B", "H", "W", "C", "Cs", "needs_grad", "tag", "seg")
+    __slots__ = ("t", "B", "H", "W", "C", "Cs", "needs_grad", "tag", "seg", "cons", "bn_src")
 
     def __init__(self, t, C, needs_grad=False, tag=""):
         self.t = t
@@ -93,6 +93,8 @@ class Act(object):
         self.needs_grad = needs_grad
         self.tag = tag
         self.seg = None          # (flat buffer, index) when this activation is one level of a pyramid group (alloc_seg)
+        self.cons = 0            # gradient contributions still to come in backward (engine: last-contributor detection)
+        self.bn_src = None       # (y, BNState, relu, has_residual) when this is the output of a BatchNorm
 
     @staticmethod
     def empty(B, H, W, C, dtype, device, needs_grad=False, tag=""):
@@ -296,7 +298,7 @@ def conv_out_hw(H, W, R, S, stride, pad):
 
 def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, res=None, res_mode=0,
                  want_stats=False, out_f32=False, out=None, accumulate=False, mode=0, out_hw=None,
-                 cin=None, x_geom=None, y_geom=None, cout_store=None, needs_grad=False, tag=""):
+                 cin=None, x_geom=None, y_geom=None, cout_store=None, needs_grad=False, tag="", bnb=None):
     """Implicit-GEMM convolution.  x: Act.  w: compute-dtype tensor laid out [Cout][R][S][Cin].
 
     mode 0 = forward gather, mode 1 = dgrad gather (then ``out_hw`` is the input-gradient size and
@@ -351,6 +353,18 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         tiles = call("mpn_conv_stats_tiles", ctypes.byref(p))
         stats = torch.empty((tiles, Cout, 2), dtype=torch.float32, device=dev)
         p.stats = stats.data_ptr()
+    if bnb is not None:
+        # this launch completes dz of a BatchNorm: its backward statistics ride in the epilogue (returned in the stats slot)
+        by, bz, st, relu = bnb
+        assert y_geom is None and not out_f32 and by.t.shape == out.t.shape and by.t.dtype == out.t.dtype
+        tiles = call("mpn_conv_stats_tiles", ctypes.byref(p))
+        stats = torch.empty((tiles, Cout, 2), dtype=torch.float32, device=dev)
+        p.bnb_partial = stats.data_ptr()
+        p.bnb_y = by.t.data_ptr()
+        p.bnb_z = bz.t.data_ptr() if bz is not None else None
+        p.bnb_mean, p.bnb_invstd = st.mean.data_ptr(), st.invstd.data_ptr()
+        p.bnb_scale, p.bnb_shift = st.scale.data_ptr(), st.shift.data_ptr()
+        p.bnb_relu = 1 if relu else 0
     if KERNEL_EVENTS.on:
         e0 = KERNEL_EVENTS.begin()
         call("mpn_conv_forward", ctypes.byref(p), stream_ptr())
@@ -359,7 +373,7 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         live = (R * S) / float(stride * stride) if mode == 1 else R * S
         flops = 2.0 * x.B * Ho * Wo * Cout * live * min(Cin, x.C if x_geom is None else Cin)
         # the name rocprofv3 prints for this instantiation (tools/rocprof_summary.py spelling)
-        general = (scale is not None or bias is not None or res is not None or accumulate or act != 0 or Cout % tc != 0)
+        general = (scale is not None or bias is not None or res is not None or accumulate or act != 0 or Cout % tc != 0 or bnb is not None)
         name = "conv_igemm_kernel<%s, %d, 128, %s, %s>" % (dtype_name(dt), tc,
                                                           "true" if p.out_f32 else "false", "true" if general else "false")
         if KERNEL_EVENTS.detail:
@@ -487,19 +501,25 @@ def bn_act(y, st, relu, res=None, needs_grad=False, tag=""):
     return z
 
 
-def bn_backward(dz, z, y, st, gamma, relu, train, dgamma=None, dbeta=None, want_dy=True, dres=None, dres_acc=False, remask=False):
+def bn_backward(dz, z, y, st, gamma, relu, train, dgamma=None, dbeta=None, want_dy=True, dres=None, dres_acc=False, remask=False,
+                partial=None):
     """Returns dy (Act or None).  dres (Act) receives/accumulates g = dz*(z>0).  remask=True (forward without a
-    residual input): the ReLU mask is recomputed from y and the forward's scale/shift instead of reading z."""
+    residual input): the ReLU mask is recomputed from y and the forward's scale/shift instead of reading z.
+    partial: per-tile (sum g, sum g*xhat) already produced by the launch that wrote dz (conv_forward(bnb=...)); the
+    reduction pass over dz / y / z is skipped."""
     dev = y.t.device
     P, C, Cs = y.P, y.C, y.Cs
     dc = dtype_code(y.t.dtype)
     k1, k2, k3 = st.scale, None, None        # frozen BN, no parameter gradients: dy = g * gamma * invstd
     if train or dgamma is not None or dbeta is not None:
-        chunks = call("mpn_bn_bwd_chunks", P, Cs, dc)
-        part = workspace(chunks * C * 2 * 4, dev, slot=3)
-        call("mpn_bn_bwd_reduce", ptr(dz.t), ptr(z.t) if (relu and not remask) else None, ptr(y.t), ptr(st.mean), ptr(st.invstd),
-             ptr(st.scale) if remask else None, ptr(st.shift) if remask else None, ptr(part),
-             chunks, P, C, Cs, 1 if relu else 0, dc, stream_ptr())
+        if partial is not None:
+            part, chunks = partial, partial.shape[0]
+        else:
+            chunks = call("mpn_bn_bwd_chunks", P, Cs, dc)
+            part = workspace(chunks * C * 2 * 4, dev, slot=3)
+            call("mpn_bn_bwd_reduce", ptr(dz.t), ptr(z.t) if (relu and not remask) else None, ptr(y.t), ptr(st.mean), ptr(st.invstd),
+                 ptr(st.scale) if remask else None, ptr(st.shift) if remask else None, ptr(part),
+                 chunks, P, C, Cs, 1 if relu else 0, dc, stream_ptr())
         coef = torch.empty((3, C), dtype=torch.float32, device=dev) if train else None
         call("mpn_bn_bwd_finalize", ptr(part), chunks, C, P, ptr(gamma), ptr(st.mean), ptr(st.invstd), 1 if train else 0,
              ptr(dgamma), ptr(dbeta), ptr(coef), stream_ptr())

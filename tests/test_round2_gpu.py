@@ -388,3 +388,50 @@ def test_pyramid_towers_equal_the_per_level_launches(dtype):
     i = m._arena.index[id(w)]
     seg = slice(m._arena.offsets[i], m._arena.offsets[i] + m._arena.sizes[i])
     assert float((g0[seg] - g1[seg]).norm() / g0[seg].norm()) <= (1e-6 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("dtype,mode", [(torch.bfloat16, "train"), (torch.float32, "train"), (torch.bfloat16, "frozen_affine")])
+def test_bn_backward_statistics_in_the_dgrad_epilogue(dtype, mode):
+    """The launch that completes dz of a BatchNorm also produces (sum g, sum g*xhat) per pixel tile (MpnConvParams.bnb_*), so
+    mpn_bn_bwd_reduce's pass over dz / y / z disappears.  Same training step with the fusion on and off: loss identical, the
+    whole gradient arena equal up to the summation order of the per-channel statistics."""
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    m, inputs, gts = _train_setup(101, dtype, 2, 160, seed=150)
+    if mode == "frozen_affine":
+        m.freeze_bn()                    # eval-mode statistics, gamma/beta still trained: statistics are needed for dgamma/dbeta only
+    res = []
+    calls = []
+    from multiposenet.pytorch_amd import _lib
+    orig = _lib.call
+
+    def counting(name, *a):
+        if name == "mpn_bn_bwd_reduce":
+            calls[-1] += 1
+        return orig(name, *a)
+    import multiposenet.pytorch_amd.ops as ops_mod
+    ops_mod.call = counting
+    try:
+        for fused in (False, True):
+            calls.append(0)
+            m._engine.fuse_bn_stats = fused
+            bn_state = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k} if not res else res[0][2]
+            m.load_state_dict(bn_state, strict=False)
+            m._arena.ensure_grads()
+            m._arena.grad_flat.zero_()
+            pred, saved = m(*inputs)
+            loss, log = poseNet.build_loss(saved, *gts)
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((loss.detach().clone(), m._arena.grad_flat.clone(), bn_state))
+    finally:
+        ops_mod.call = orig
+        m._engine.fuse_bn_stats = True
+        m.train()
+    (l0, g0, _), (l1, g1, _) = res
+    assert torch.equal(l0, l1)
+    nbn = len(m._bns)
+    assert calls[0] == nbn and calls[1] <= 8, "separate reductions: %d without fusion (%d BN layers), %d with" % (calls[0], nbn, calls[1])
+    rel = float((g0 - g1).norm() / g0.norm())
+    report("BN backward statistics in the dgrad epilogue (%s, %s): %d -> %d separate reduction launches, gradient arena rel-L2 %.2e"
+           % (str(dtype), mode, calls[0], calls[1], rel))
+    assert rel <= (2e-5 if dtype == torch.float32 else 1e-2)
