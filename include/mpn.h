@@ -48,7 +48,9 @@ typedef struct MpnConvParams {
     int32_t Ho, Wo, Cout, Cout_store; /* output dims; channels [Cout, Cout_store) are written 0   */
     int32_t R, S, stride, pad;
     int32_t mode;         /* 0: hi = ho*stride - pad + r ; 1 (dgrad): hi = (ho + pad - r)/stride   */
-    int32_t act;          /* 0 none, 1 relu, 2 sigmoid                                            */
+    int32_t act;          /* 0 none, 1 relu, 2 sigmoid (both before the residual stage), 3 relu AFTER a same-size
+                           * residual add: with scale/bias = folded BatchNorm this is a whole Bottleneck tail
+                           * relu(bn3(conv3(x)) + shortcut) (network/fpn.py:30-33) in one launch (frozen statistics) */
     int32_t res_mode;     /* 0 none, 1 same size, 2 nearest-upsampled from [res_H, res_W]          */
     int32_t res_H, res_W;
     int32_t accumulate;   /* y = y + result (act must be 0)                                       */

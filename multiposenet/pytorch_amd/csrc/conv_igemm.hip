@@ -298,6 +298,10 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
 #pragma unroll
                         for (int e = 0; e < EV; ++e) a.v[e] += r.v[e];
                     }
+                    if (p.act == 3) {                            // ReLU AFTER the residual add: relu(bn3(conv3(.)) + shortcut), fpn.py:30-33
+#pragma unroll
+                        for (int e = 0; e < EV; ++e) a.v[e] = fmaxf(a.v[e], 0.f);
+                    }
                     a.store(reinterpret_cast<OT*>(&v));
                 }
                 *reinterpret_cast<u32x4_t*>(dst) = v;
@@ -611,9 +615,10 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     MPN_CHECK_ARG(p.R > 0 && p.S > 0 && p.stride >= 1);
     MPN_CHECK_ARG(p.mode == 0 || (p.mode == 1 && (p.stride == 1 || p.stride == 2)));
     MPN_CHECK_ARG(!(p.accumulate && p.act != 0));
+    MPN_CHECK_ARG(p.act >= 0 && p.act <= 3 && (p.act != 3 || p.res_mode == 1));
     MPN_CHECK_ARG(p.res_mode == 0 || p.res != nullptr);
     MPN_CHECK_ARG(!(p.stats && (p.bias || p.scale || p.res_mode || p.accumulate || p.act)));
-    MPN_CHECK_ARG(!((p.res_mode || p.accumulate) && p.act));
+    MPN_CHECK_ARG(!((p.res_mode || p.accumulate) && p.act && p.act != 3));
     MPN_CHECK_ARG(!p.bnb_partial || (p.bnb_y && p.bnb_mean && p.bnb_invstd && !p.out_f32 && !p.nseg && !p.stats && !p.act &&
                                      (!p.bnb_relu || p.bnb_z || (p.bnb_scale && p.bnb_shift))));
     {   // buffer descriptors address at most 4 GB per operand

@@ -81,6 +81,8 @@ class Engine(object):
         self.pyramid_towers = os.environ.get("MPN_PYRAMID_TOWERS", "1") != "0"
         # BatchNorm-backward statistics ride in the epilogue of the dgrad launch that completes dz (no separate reduction pass)
         self.fuse_bn_stats = os.environ.get("MPN_BN_FUSED_STATS", "1") != "0"
+        # inference with frozen statistics: BatchNorm (+ReLU, + the bottleneck's residual add) folds into the conv epilogue
+        self.fold_bn = os.environ.get("MPN_FOLD_BN", "1") != "0"
 
     def side_stream(self, device):
         """Second HIP stream for weight/bias gradients.  They are off the backward critical path (only the
@@ -542,6 +544,10 @@ class Engine(object):
         Ho, Wo = ops.conv_out_hw(H, W, 7, 7, 2, 3)
         geom = (Hp, Wp, Hp * Wp * 4, Wp * 4, 4)
         bn_train = f.bn1.training
+        if self.fold_bn and not ctx.train and not bn_train:        # frozen statistics, no tape: bn1 + ReLU in the stem's epilogue
+            bst = ops.bn_finalize_eval(f.bn1.weight.data, f.bn1.bias.data, f.bn1.running_mean, f.bn1.running_var, f.bn1.eps)
+            z, _ = ops.conv_forward(xa, wp, 64, 7, 1, 2, 0, cin=32, x_geom=geom, out_hw=(Ho, Wo), scale=bst.scale, bias=bst.shift, act=1)
+            return self.maxpool(ctx, z)
         y, st = ops.conv_forward(xa, wp, 64, 7, 1, 2, 0, cin=32, x_geom=geom, out_hw=(Ho, Wo), want_stats=bn_train)
         if ctx.train and w.requires_grad:
             y.needs_grad = True
@@ -562,19 +568,26 @@ class Engine(object):
         z = self.bn(ctx, y, st, f.bn1, True)
         return self.maxpool(ctx, z)
 
+    def conv_bn(self, ctx, x, conv, bn, relu, res=None):
+        """act(bn(conv(x)) [+ res]).  Without a tape and with frozen statistics this is ONE launch: the BatchNorm becomes the
+        epilogue's per-channel scale / shift (f32, before any rounding), ReLU and the residual add follow in registers; otherwise
+        conv (+ statistics) and the BatchNorm passes."""
+        if self.fold_bn and not ctx.train and not bn.training:
+            st = ops.bn_finalize_eval(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.eps)
+            O, I, R, S, stride, pad = _geom(conv)
+            act = (3 if res is not None else 1) if relu else 0
+            y, _ = ops.conv_forward(x, self.w_fwd(conv), O, R, S, stride, pad, scale=st.scale, bias=st.shift, act=act,
+                                    res=res, res_mode=1 if res is not None else 0)
+            return y
+        y, s = self.conv(ctx, x, conv, stats=bn.training)
+        return self.bn(ctx, y, s, bn, relu, res=res)
+
     def bottleneck(self, ctx, x, blk):
         """fpn.py:28-34."""
-        y1, s1 = self.conv(ctx, x, blk.conv1, stats=blk.bn1.training)
-        z1 = self.bn(ctx, y1, s1, blk.bn1, True)
-        y2, s2 = self.conv(ctx, z1, blk.conv2, stats=blk.bn2.training)
-        z2 = self.bn(ctx, y2, s2, blk.bn2, True)
-        y3, s3 = self.conv(ctx, z2, blk.conv3, stats=blk.bn3.training)
-        if len(blk.downsample) > 0:
-            ys, ss = self.conv(ctx, x, blk.downsample[0], stats=blk.downsample[1].training)
-            sc = self.bn(ctx, ys, ss, blk.downsample[1], False)
-        else:
-            sc = x
-        return self.bn(ctx, y3, s3, blk.bn3, True, res=sc)
+        z1 = self.conv_bn(ctx, x, blk.conv1, blk.bn1, True)
+        z2 = self.conv_bn(ctx, z1, blk.conv2, blk.bn2, True)
+        sc = self.conv_bn(ctx, x, blk.downsample[0], blk.downsample[1], False) if len(blk.downsample) > 0 else x
+        return self.conv_bn(ctx, z2, blk.conv3, blk.bn3, True, res=sc)
 
     def backbone(self, ctx, img):
         f = self.m.fpn

@@ -435,3 +435,27 @@ def test_bn_backward_statistics_in_the_dgrad_epilogue(dtype, mode):
     report("BN backward statistics in the dgrad epilogue (%s, %s): %d -> %d separate reduction launches, gradient arena rel-L2 %.2e"
            % (str(dtype), mode, calls[0], calls[1], rel))
     assert rel <= (2e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_folded_batchnorm_inference_equals_the_separate_passes(dtype):
+    """Inference with frozen statistics folds BatchNorm (+ReLU, + the residual add of a Bottleneck, fpn.py:28-34) into the
+    conv epilogue (act code 3).  Same network, fold on / off: fp32 agrees to rounding (the fold skips one rounding of y),
+    fp16 within its own precision."""
+    from oracle import weightgen
+    m = get_model(101, dtype)
+    m.eval()
+    img = t(weightgen.gen_images(160, 2, 192, 160)).cuda()
+    outs = []
+    for fold in (False, True):
+        m._engine.fold_bn = fold
+        with torch.no_grad():
+            heat, _ = m([img, "keypoint_subnet"])
+            _, ds = m([img, "detection_subnet"])
+        outs.append((heat.float().clone(), ds[0].float().clone(), ds[1].float().clone()))
+    m._engine.fold_bn = True
+    lim = 2e-5 if dtype == torch.float32 else 5e-3
+    for name, a, b in zip(("heat", "cls", "reg"), outs[0], outs[1]):
+        rel = float((a - b).norm() / b.norm())
+        report("folded BN (%s) %s: rel-L2 vs separate passes %.2e" % (str(dtype), name, rel))
+        assert rel <= lim

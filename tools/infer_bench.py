@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 on one MI355X: R101 'both' inference, 640x640, batch 64, fp16, with NMS for every image, heat-map peak
+extraction and the PRN assignment.  Prints one JSON line per stage set.
+usage: python tools/infer_bench.py [--batch 64] [--size 640] [--dtype f16] [--iters 10] [--no-fold]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"])
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--no-fold", action="store_true")
+    args = ap.parse_args()
+    from multiposenet.pytorch_amd.evaluate.prn_process import prn_process_batch
+    from multiposenet.pytorch_amd.network.joint_utils import NMS_batch
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    from oracle import weightgen
+    import bench
+    torch.cuda.set_device(0)
+    dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
+    m = poseNet(101, compute_dtype=dt).cuda()
+    bench.he_weights(m)
+    sd = weightgen.gen_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items() if k.startswith("prn.")}, seed=3, flavour="he")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    m.eval()
+    m._engine.fold_bn = not args.no_fold
+    img = torch.from_numpy(weightgen.gen_images(41, args.batch, args.size, args.size)).cuda()
+
+    def net():
+        with torch.no_grad():
+            return m.forward_all_images(img)
+
+    def full():
+        heat, dets = net()
+        peaks = NMS_batch({'thre1': 0.1}, heat, 4.0)
+        kps, boxes = [], []
+        for b in range(args.batch):
+            rows = [tuple(p) + (j,) for j, pj in enumerate(peaks[b]) for p in pj[:20]]          # cap the noise peaks of random weights
+            kps.append([[r[0], r[1], r[2], r[3], max(0, r[4] - 1)] for r in rows if r[4] != 1])
+            bx = dets[b][2][dets[b][0] > 0.5][:8] if dets[b][0].numel() else []
+            boxes.append([[float(v) for v in bb] for bb in bx if bb[2] - bb[0] >= 1 and bb[3] - bb[1] >= 1])
+        return prn_process_batch(m, kps, boxes)
+    for name, fn in (("network + NMS for every image", net), ("+ heat-map peaks + PRN assignment", full)):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.iters):
+            fn()
+        torch.cuda.synchronize()
+        dtm = (time.perf_counter() - t0) / args.iters
+        print(json.dumps({"stage": name, "images_per_sec": round(args.batch / dtm, 1), "ms_per_batch": round(dtm * 1e3, 2), "batch": args.batch,
+                          "size": args.size, "dtype": args.dtype, "bn_folded": not args.no_fold}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
