@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"])
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-fold", action="store_true")
+    ap.add_argument("--candidates", type=int, default=1000, help="anchors per image above the 0.05 score threshold (the classification bias "
+                    "of the random-weight network is shifted to get there; a trained detector passes a few hundred)")
     args = ap.parse_args()
     from multiposenet.pytorch_amd.evaluate.prn_process import prn_process_batch
     from multiposenet.pytorch_amd.network.joint_utils import NMS_batch
@@ -35,6 +37,22 @@ def main():
     m.eval()
     m._engine.fold_bn = not args.no_fold
     img = torch.from_numpy(weightgen.gen_images(41, args.batch, args.size, args.size)).cuda()
+    # calibrate the detector's output bias: a uniform logit shift so that ~args.candidates anchors per image exceed 0.05
+    with torch.no_grad():
+        _, (cls, _, _) = m([img[:4].contiguous(), "detection_subnet"])
+        s = cls.float().flatten().clamp(1e-6, 1 - 1e-6)
+        q = torch.quantile(s[torch.randperm(s.numel(), device=s.device)[:1000000]], 1.0 - args.candidates / float(cls.shape[1]))
+        shift = float(np.log(0.05 / 0.95) - torch.log(q / (1 - q)))
+        m.classificationModel.output.bias.data += shift
+
+    def net_only():
+        with torch.no_grad():
+            m._prepare(img)
+            from multiposenet.pytorch_amd.engine import Ctx
+            eng, ctx = m._engine, Ctx(False)
+            c2, c3, c4, c5 = eng.backbone(ctx, img)
+            heat, _ = eng.keypoint_head(ctx, eng.kp_pyramid(ctx, c2, c3, c4, c5), False)
+            return heat, eng.detection_head(ctx, eng.det_pyramid(ctx, c3, c4, c5))
 
     def net():
         with torch.no_grad():
@@ -50,7 +68,8 @@ def main():
             bx = dets[b][2][dets[b][0] > 0.5][:8] if dets[b][0].numel() else []
             boxes.append([[float(v) for v in bb] for bb in bx if bb[2] - bb[0] >= 1 and bb[3] - bb[1] >= 1])
         return prn_process_batch(m, kps, boxes)
-    for name, fn in (("network + NMS for every image", net), ("+ heat-map peaks + PRN assignment", full)):
+    for name, fn in (("network only (backbone, both pyramids, both heads)", net_only), ("network + decode + NMS for every image", net),
+                     ("+ heat-map peaks + PRN assignment", full)):
         fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -59,7 +78,7 @@ def main():
         torch.cuda.synchronize()
         dtm = (time.perf_counter() - t0) / args.iters
         print(json.dumps({"stage": name, "images_per_sec": round(args.batch / dtm, 1), "ms_per_batch": round(dtm * 1e3, 2), "batch": args.batch,
-                          "size": args.size, "dtype": args.dtype, "bn_folded": not args.no_fold}), flush=True)
+                          "size": args.size, "dtype": args.dtype, "bn_folded": not args.no_fold, "candidates_per_image": args.candidates}), flush=True)
 
 
 if __name__ == "__main__":
