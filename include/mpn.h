@@ -81,6 +81,24 @@ typedef struct MpnConvParams {
     const float* bnb_shift;
     float* bnb_partial;
     int32_t bnb_relu;
+    /* In-launch finalize (fin_counters != NULL, together with `stats` or `bnb_partial`): the LAST workgroup to finish a tile
+     * of output channels reduces that tile's per-pixel-tile partials (fixed order, double precision — deterministic whatever
+     * the arrival order) and does the work of mpn_bn_finalize_train (stats: fin_out = [4][Cout] mean, invstd, scale, shift;
+     * running statistics updated when fin_rm / fin_rv are given) or of mpn_bn_bwd_finalize (bnb_partial: fin_dgamma += ,
+     * fin_dbeta += , fin_out = [3][Cout] k1, k2, k3 with fin_train selecting batch-statistics or frozen coefficients; mean /
+     * invstd are bnb_mean / bnb_invstd).  fin_counters: one zeroed uint32 per output-channel tile (>= 64 entries cover every
+     * shape); the launch leaves them zero again.  Launches sharing a counter array must be ordered (one stream).           */
+    uint32_t* fin_counters;
+    const float* fin_gamma;
+    const float* fin_beta;
+    float* fin_rm;
+    float* fin_rv;
+    float* fin_out;
+    float* fin_dgamma;
+    float* fin_dbeta;
+    double fin_count;
+    float fin_momentum, fin_eps;
+    int32_t fin_train;
 } MpnConvParams;
 #define MPN_MAX_SEG 5
 

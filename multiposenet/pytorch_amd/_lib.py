@@ -39,6 +39,9 @@ class ConvParams(ctypes.Structure):
         ("seg_x", ctypes.c_void_p * 5), ("seg_y", ctypes.c_void_p * 5),
         ("bnb_y", ctypes.c_void_p), ("bnb_z", ctypes.c_void_p), ("bnb_mean", ctypes.c_void_p), ("bnb_invstd", ctypes.c_void_p),
         ("bnb_scale", ctypes.c_void_p), ("bnb_shift", ctypes.c_void_p), ("bnb_partial", ctypes.c_void_p), ("bnb_relu", ctypes.c_int32),
+        ("fin_counters", ctypes.c_void_p), ("fin_gamma", ctypes.c_void_p), ("fin_beta", ctypes.c_void_p), ("fin_rm", ctypes.c_void_p),
+        ("fin_rv", ctypes.c_void_p), ("fin_out", ctypes.c_void_p), ("fin_dgamma", ctypes.c_void_p), ("fin_dbeta", ctypes.c_void_p),
+        ("fin_count", ctypes.c_double), ("fin_momentum", ctypes.c_float), ("fin_eps", ctypes.c_float), ("fin_train", ctypes.c_int32),
     ]
 
 

@@ -125,6 +125,98 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// A per-tile statistics pair.  When the launch finalizes in place (fin_counters) it is published write-through (one 8-byte
+// agent-scope store: cdna_hip_programming.md, Guideline 16 recipe R1) so that the last-arriving workgroup — on any XCD — reads it
+// after its acquire.
+__device__ __forceinline__ void store_partial(float* dst, float a, float b, bool publish) {
+    if (publish) {
+        const unsigned long long bits = ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *reinterpret_cast<float2*>(dst) = make_float2(a, b);
+    }
+}
+
+// In-launch finalize (mpn.h: fin_*).  Every workgroup of channel tile `tc` has published its partial pair per channel; the one that
+// draws the last ticket reduces the column [ntiles][TC] in a fixed order (SL interleaved slices per channel in double precision,
+// combined in slice order) — the same numbers whichever workgroup arrives last — and writes the BatchNorm coefficients.
+template <int TC>
+__device__ __forceinline__ void fin_last_arriver(const MpnConvParams& p, int c0, int tc, int ntiles, unsigned char* lds) {
+    constexpr int SL = 256 / TC;                               // slices per channel (256 threads)
+    volatile int* flag = reinterpret_cast<volatile int*>(lds + 12288);
+    double* lds_d = reinterpret_cast<double*>(lds);            // [SL][TC][2]
+    const int t = threadIdx.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its write-through stores
+    __syncthreads();
+    if (t == 0) {
+        const unsigned old = __hip_atomic_fetch_add(p.fin_counters + tc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = (old == (unsigned)(ntiles - 1)) ? 1 : 0;
+    }
+    __syncthreads();
+    if (*flag == 0) return;
+    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    const float* __restrict__ part = p.stats ? p.stats : p.bnb_partial;
+    const int cl = t % TC, sl = t / TC;
+    const int c = c0 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < p.Cout) {
+        const float* col = part + (long)c * 2;
+        const long stride = (long)p.Cout * 2;
+        int tile = sl;
+        for (; tile + 7 * SL < ntiles; tile += 8 * SL) {       // eight loads in flight per thread
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2*>(col + (long)(tile + u * SL) * stride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
+        }
+        for (; tile < ntiles; tile += SL) {
+            const float2 v = *reinterpret_cast<const float2*>(col + (long)tile * stride);
+            s1 += (double)v.x; s2 += (double)v.y;
+        }
+    }
+    if (SL > 1) {
+        lds_d[(sl * TC + cl) * 2 + 0] = s1;
+        lds_d[(sl * TC + cl) * 2 + 1] = s2;
+        __syncthreads();
+        if (sl == 0) {
+            s1 = 0.0; s2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < SL; ++k) { s1 += lds_d[(k * TC + cl) * 2 + 0]; s2 += lds_d[(k * TC + cl) * 2 + 1]; }
+        }
+    }
+    if (sl == 0 && c < p.Cout) {
+        const int C = p.Cout;
+        const float gm = p.fin_gamma ? p.fin_gamma[c] : 1.f;
+        if (p.stats) {                                          // mpn_bn_finalize_train's arithmetic
+            const double mu = s1 / p.fin_count;
+            double var = s2 / p.fin_count - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const float is = (float)(1.0 / sqrt(var + (double)p.fin_eps));
+            const float b = p.fin_beta ? p.fin_beta[c] : 0.f;
+            const float sc = gm * is;
+            p.fin_out[c] = (float)mu; p.fin_out[C + c] = is; p.fin_out[2 * C + c] = sc; p.fin_out[3 * C + c] = b - (float)mu * sc;
+            if (p.fin_rm) p.fin_rm[c] = (1.f - p.fin_momentum) * p.fin_rm[c] + p.fin_momentum * (float)mu;
+            if (p.fin_rv) {
+                const double unb = p.fin_count > 1.0 ? var * p.fin_count / (p.fin_count - 1.0) : var;
+                p.fin_rv[c] = (1.f - p.fin_momentum) * p.fin_rv[c] + p.fin_momentum * (float)unb;
+            }
+        } else {                                                // mpn_bn_bwd_finalize's arithmetic
+            if (p.fin_dbeta) p.fin_dbeta[c] += (float)s1;
+            if (p.fin_dgamma) p.fin_dgamma[c] += (float)s2;
+            if (p.fin_out) {
+                const float is = p.bnb_invstd[c], mu = p.bnb_mean[c];
+                const float a = (float)(s1 / p.fin_count), b = (float)(s2 / p.fin_count);
+                p.fin_out[c] = gm * is;
+                p.fin_out[C + c] = p.fin_train ? -gm * is * is * b : 0.f;
+                p.fin_out[2 * C + c] = p.fin_train ? gm * is * (mu * is * b - a) : 0.f;
+            }
+        }
+    }
+    if (t == 0) __hip_atomic_store(p.fin_counters + tc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Epilogue.  Phase A (accumulator layout: lane = 4 consecutive couts of one pixel): scale, bias, residual,
 // accumulate, activation — branch-free per element (uniform conditions only); skipped entirely for the plain
 // conv+BN-stats case.  BN partial sums use DPP row reductions.  Phase B: the finished tile goes through a
@@ -132,7 +224,10 @@ __device__ __forceinline__ float row16_sum(float v) {
 // channels (full 128-byte lines per wave-instruction).
 template <typename T, typename OT, int TC, int TP, bool GENERAL>
 __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&acc)[ConvCfg<T, TC, TP>::MC][ConvCfg<T, TC, TP>::MP],
-                                              int c0, long p0, int wc, int wp, int lane, int tp, unsigned char* lds, const int dbg) {
+                                              int c0, long p0, int wc, int wp, int lane, int tp, unsigned char* lds, const int dbg,
+                                              int tc, int ntiles, const MpnConvParams& pk) {
+    // bnb_* / fin_* are read from the kernel-argument struct `pk` (late scalar loads), never from the patched working copy `p`:
+    // fields the copy never reads are not kept in scalar registers through the main loop
     using C = ConvCfg<T, TC, TP>;
     constexpr int OSZ = (int)sizeof(OT);
     constexpr int PASS_TILES = (OSZ == 4) ? ((C::MP >= 2) ? C::MP / 2 : 1) : C::MP;   // pixel tiles staged per pass
@@ -227,7 +322,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                     a += lds_f[(w * TC + t) * 2 + 0];
                     q += lds_f[(w * TC + t) * 2 + 1];
                 }
-                *reinterpret_cast<float2*>(p.stats + ((long)tp * p.Cout + cout) * 2) = make_float2(a, q);
+                store_partial(p.stats + ((long)tp * p.Cout + cout) * 2, a, q, pk.fin_counters != nullptr);
             }
         }
         __syncthreads();
@@ -240,9 +335,9 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
     const int ccol = c0 + wc * C::WTC + sc_ * EV;              // first channel of this lane's chunk
     // BatchNorm-backward statistics of the tensor being completed (mpn.h: bnb_*): per-lane sums over the lane's pixels of
     // its EV channels, reduced over the tile after the store loop
-    const bool bnb = GENERAL && p.bnb_partial != nullptr;
-    const OT* __restrict__ Ybn = (const OT*)p.bnb_y;
-    const OT* __restrict__ Zbn = (const OT*)p.bnb_z;
+    const bool bnb = GENERAL && pk.bnb_partial != nullptr;
+    const OT* __restrict__ Ybn = (const OT*)pk.bnb_y;
+    const OT* __restrict__ Zbn = (const OT*)pk.bnb_z;
     float bs1[EV], bs2[EV], bmu[EV], bis[EV], bsc[EV], bsf[EV];
     if (bnb) {
 #pragma unroll
@@ -250,10 +345,10 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
             const int c = ccol + e;
             const bool live = c < p.Cout;
             bs1[e] = 0.f; bs2[e] = 0.f;
-            bmu[e] = live ? p.bnb_mean[c] : 0.f;
-            bis[e] = live ? p.bnb_invstd[c] : 0.f;
-            bsc[e] = (live && p.bnb_scale) ? p.bnb_scale[c] : 0.f;
-            bsf[e] = (live && p.bnb_shift) ? p.bnb_shift[c] : 0.f;
+            bmu[e] = live ? pk.bnb_mean[c] : 0.f;
+            bis[e] = live ? pk.bnb_invstd[c] : 0.f;
+            bsc[e] = (live && pk.bnb_scale) ? pk.bnb_scale[c] : 0.f;
+            bsf[e] = (live && pk.bnb_shift) ? pk.bnb_shift[c] : 0.f;
         }
     }
 #pragma unroll
@@ -314,7 +409,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
 #pragma unroll
                     for (int e = 0; e < EV; ++e) {
                         float g = dzv.v[e];
-                        if (p.bnb_relu) {
+                        if (pk.bnb_relu) {
                             const float zv = Zbn ? zz.v[e] : yy.v[e] * bsc[e] + bsf[e];
                             if (!(zv > 0.f)) g = 0.f;
                         }
@@ -355,9 +450,10 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                 a1 += lds_f[(w * TC + t) * 2 + 0];
                 a2 += lds_f[(w * TC + t) * 2 + 1];
             }
-            *reinterpret_cast<float2*>(p.bnb_partial + ((long)tp * p.Cout + c0 + t) * 2) = make_float2(a1, a2);
+            store_partial(pk.bnb_partial + ((long)tp * p.Cout + c0 + t) * 2, a1, a2, pk.fin_counters != nullptr);
         }
     }
+    if (pk.fin_counters) fin_last_arriver<TC>(pk, c0, tc, ntiles, lds);
 }
 
 // LDS-DMA plumbing (see conv_wgrad.hip for the probe-verified semantics): `buffer_load_dwordx4 ... lds` writes
@@ -534,8 +630,9 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_kernel(const
     __syncthreads();                          // the epilogue re-uses the ring as its staging area
 
     if (dbg & 16) { if (acc[0][0][0] == 123.456f) ((float*)p.y)[0] = 1.f; return; }   // ablation: no epilogue
-    if (OUTF32) conv_epilogue<T, float, TC, TP, GENERAL>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg);
-    else        conv_epilogue<T, T, TC, TP, GENERAL>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg);
+    const int ntiles = (int)(gridDim.x / (unsigned)tilesC);       // pixel tiles of the launch (in-launch finalize)
+    if (OUTF32) conv_epilogue<T, float, TC, TP, GENERAL>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
+    else        conv_epilogue<T, T, TC, TP, GENERAL>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
 }
 
 constexpr int kTP = 128;
@@ -619,6 +716,8 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     MPN_CHECK_ARG(p.res_mode == 0 || p.res != nullptr);
     MPN_CHECK_ARG(!(p.stats && (p.bias || p.scale || p.res_mode || p.accumulate || p.act)));
     MPN_CHECK_ARG(!((p.res_mode || p.accumulate) && p.act && p.act != 3));
+    MPN_CHECK_ARG(!p.fin_counters || (((p.stats != nullptr) != (p.bnb_partial != nullptr)) && p.fin_count > 0 && !p.nseg &&
+                                      (p.stats ? p.fin_out != nullptr : true)));
     MPN_CHECK_ARG(!p.bnb_partial || (p.bnb_y && p.bnb_mean && p.bnb_invstd && !p.out_f32 && !p.nseg && !p.stats && !p.act &&
                                      (!p.bnb_relu || p.bnb_z || (p.bnb_scale && p.bnb_shift))));
     {   // buffer descriptors address at most 4 GB per operand

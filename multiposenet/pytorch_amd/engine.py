@@ -37,6 +37,8 @@ class Ctx(object):
         self.side_pending = []   # closures waiting for the next fork point (Engine.fork_every > 1)
         self.wt_ready = None     # event: the transposed weight copies (made on the side stream) are complete
         self.bnb = {}            # id(BN output Act) -> per-tile backward statistics produced by the launch that completed its gradient
+        self.side_deferred = []  # side-stream closures held back for later fork points (Engine.side_defer)
+        self.side_count = 0
 
     def gbuf(self, act, dtype=None):
         """Gradient buffer for ``act``: returns (Act, existed)."""
@@ -77,12 +79,19 @@ class Engine(object):
         # side-stream work is handed over in groups of `fork_every` layers (one event record / wait per group): a captured
         # hipGraph pays for every cross-stream edge, the eager tape does not care much
         self.fork_every = max(1, int(os.environ.get("MPN_SIDE_FORK_EVERY", "1")))
+        # scheduling experiment: hold back the first `side_defer` weight-gradient closures of a backward pass (the heads' MFMA-bound
+        # ones, which otherwise compete with the heads' equally MFMA-bound dgrads) and release `side_release` of them per later
+        # fork point, beside the HBM-bound BatchNorm passes of the backbone
+        self.side_defer = int(os.environ.get("MPN_SIDE_DEFER", "0"))
+        self.side_release = max(1, int(os.environ.get("MPN_SIDE_RELEASE", "1")))
         # the RetinaNet towers share their weights over p3..p7: one launch per layer over the whole pyramid instead of one per level
         self.pyramid_towers = os.environ.get("MPN_PYRAMID_TOWERS", "1") != "0"
         # BatchNorm-backward statistics ride in the epilogue of the dgrad launch that completes dz (no separate reduction pass)
         self.fuse_bn_stats = os.environ.get("MPN_BN_FUSED_STATS", "1") != "0"
         # inference with frozen statistics: BatchNorm (+ReLU, + the bottleneck's residual add) folds into the conv epilogue
         self.fold_bn = os.environ.get("MPN_FOLD_BN", "1") != "0"
+        # the BatchNorm finalize steps (tile partials -> coefficients) run inside the producing conv launch (last-arriving workgroup)
+        self.fuse_bn_finalize = os.environ.get("MPN_BN_FUSED_FINALIZE", "1") != "0"
 
     def side_stream(self, device):
         """Second HIP stream for weight/bias gradients.  They are off the backward critical path (only the
@@ -104,7 +113,14 @@ class Engine(object):
             fn()
             return
         ctx.side_keep.append(keep)
+        ctx.side_count += 1
+        if ctx.side_count <= self.side_defer and self.m._reducer is None:
+            ctx.side_deferred.append((fn, torch_ops))
+            return
         ctx.side_pending.append((fn, torch_ops))
+        if ctx.side_deferred:
+            ctx.side_pending.extend(ctx.side_deferred[:self.side_release])
+            del ctx.side_deferred[:self.side_release]
         if len(ctx.side_pending) >= self.fork_every:
             self.flush_side(ctx, device)
 
@@ -234,11 +250,18 @@ class Engine(object):
             self.m._reducer.param_ready(p)
 
     # ------------------------------------------------------------------ ops
-    def conv(self, ctx, x, layer, act=0, res=None, res_mode=0, stats=False, out_f32=False, tag=""):
+    def _bn_fin(self, bn):
+        """Arguments of the in-launch forward finalize for BatchNorm layer `bn` (train mode)."""
+        if bn is None or not self.fuse_bn_finalize:
+            return None
+        return (bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+
+    def conv(self, ctx, x, layer, act=0, res=None, res_mode=0, stats=False, out_f32=False, tag="", bn=None):
         O, I, R, S, stride, pad = _geom(layer)
         bias = layer.bias
         y, st = ops.conv_forward(x, self.w_fwd(layer), O, R, S, stride, pad, bias=bias.data if bias is not None else None,
-                                 act=act, res=res, res_mode=res_mode, want_stats=stats, out_f32=out_f32, tag=tag)
+                                 act=act, res=res, res_mode=res_mode, want_stats=stats, out_f32=out_f32, tag=tag,
+                                 bn_fin=self._bn_fin(bn) if stats else None)
         if ctx.train:
             y.needs_grad = bool(x.needs_grad or layer.weight.requires_grad or (bias is not None and bias.requires_grad)
                                 or (res is not None and res.needs_grad))
@@ -305,9 +328,15 @@ class Engine(object):
             bnb = None
             if x.cons == 0 and x.bn_src is not None and self.fuse_bn_stats:
                 # this launch completes dz of the BatchNorm that produced x: its backward statistics ride in the epilogue
-                by, st, relu, has_res, wants_stats = x.bn_src
+                by, st, relu, has_res, wants_stats, bn_layer, train_stats = x.bn_src
                 if wants_stats and by.t.dtype == g.t.dtype:
-                    bnb = (by, x if (relu and has_res) else None, st, relu)
+                    fin = None
+                    if self.fuse_bn_finalize:
+                        ar = self.m._arena
+                        fin = (bn_layer.weight.data, train_stats,
+                               ar.grad_seg(bn_layer.weight) if bn_layer.weight.requires_grad else None,
+                               ar.grad_seg(bn_layer.bias) if bn_layer.bias.requires_grad else None)
+                    bnb = (by, x if (relu and has_res) else None, st, relu, fin)
             _, part = ops.conv_forward(dy, wt, I, R, S, stride, pad, mode=1, out_hw=(x.H, x.W), cin=wt.shape[3], out=g, accumulate=existed, bnb=bnb)
             if bnb is not None:
                 ctx.bnb[id(x)] = part
@@ -389,8 +418,11 @@ class Engine(object):
     def bn(self, ctx, y, stats, layer, relu, res=None, tag=""):
         train_stats = layer.training
         if train_stats:
-            st = ops.bn_finalize_train(stats, y.P, layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var,
-                                       layer.momentum if layer.momentum is not None else 0.1, layer.eps)
+            if isinstance(stats, ops.BNState):         # the conv launch finalized in place
+                st = stats
+            else:
+                st = ops.bn_finalize_train(stats, y.P, layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var,
+                                           layer.momentum if layer.momentum is not None else 0.1, layer.eps)
             ctx.bn_train_ran = True
         else:
             st = ops.bn_finalize_eval(layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var, layer.eps)
@@ -404,9 +436,18 @@ class Engine(object):
                 if res is not None and res.needs_grad:
                     res.cons += 1
                 wants_stats = bool(train_stats or layer.weight.requires_grad or layer.bias.requires_grad)
-                z.bn_src = (y, st, relu, res is not None, wants_stats)
+                z.bn_src = (y, st, relu, res is not None, wants_stats, layer, train_stats)
                 ctx.tape.append(lambda: self._bn_bwd(ctx, y, z, st, layer, relu, res, train_stats))
         return z
+
+    @staticmethod
+    def _bnb_args(fused):
+        """What the launch that completed dz left behind: nothing, per-tile partial statistics, or finished coefficients."""
+        if fused is None:
+            return {}
+        if isinstance(fused, str) or (fused.dim() == 2 and fused.shape[0] == 3):
+            return {"coef": fused}
+        return {"partial": fused}
 
     def _bn_bwd(self, ctx, y, z, st, layer, relu, res, train_stats):
         dz = ctx.pop_grad(z)
@@ -429,7 +470,7 @@ class Engine(object):
                              dgamma=ar.grad_seg(layer.weight) if wg else None,
                              dbeta=ar.grad_seg(layer.bias) if bg else None,
                              want_dy=want_dy, dres=dres, dres_acc=dres_acc, remask=bool(relu and res is None),
-                             partial=ctx.bnb.pop(id(z), None))
+                             **self._bnb_args(ctx.bnb.pop(id(z), None)))
         if wg:
             self._grad_done(ctx, layer.weight)
         if bg:
@@ -548,7 +589,8 @@ class Engine(object):
             bst = ops.bn_finalize_eval(f.bn1.weight.data, f.bn1.bias.data, f.bn1.running_mean, f.bn1.running_var, f.bn1.eps)
             z, _ = ops.conv_forward(xa, wp, 64, 7, 1, 2, 0, cin=32, x_geom=geom, out_hw=(Ho, Wo), scale=bst.scale, bias=bst.shift, act=1)
             return self.maxpool(ctx, z)
-        y, st = ops.conv_forward(xa, wp, 64, 7, 1, 2, 0, cin=32, x_geom=geom, out_hw=(Ho, Wo), want_stats=bn_train)
+        y, st = ops.conv_forward(xa, wp, 64, 7, 1, 2, 0, cin=32, x_geom=geom, out_hw=(Ho, Wo), want_stats=bn_train,
+                                 bn_fin=self._bn_fin(f.bn1) if bn_train else None)
         if ctx.train and w.requires_grad:
             y.needs_grad = True
             self._note_use(ctx, w)
@@ -579,7 +621,7 @@ class Engine(object):
             y, _ = ops.conv_forward(x, self.w_fwd(conv), O, R, S, stride, pad, scale=st.scale, bias=st.shift, act=act,
                                     res=res, res_mode=1 if res is not None else 0)
             return y
-        y, s = self.conv(ctx, x, conv, stats=bn.training)
+        y, s = self.conv(ctx, x, conv, stats=bn.training, bn=bn)
         return self.bn(ctx, y, s, bn, relu, res=res)
 
     def bottleneck(self, ctx, x, blk):
@@ -728,6 +770,8 @@ class Engine(object):
         while tape:
             tape.pop()()
         if side is not None:
+            ctx.side_pending.extend(ctx.side_deferred)
+            ctx.side_deferred = []
             self.flush_side(ctx, dev)
             gpu_op(torch.cuda.current_stream(dev).wait_stream, side)      # join: parameter gradients are complete
         ctx.grads.clear()

@@ -4,6 +4,7 @@ torch is used only as the device-memory allocator and stream provider: every fun
 raw device pointers, sizes and the current ``hipStream_t`` to ``libmpn_hip.so``.
 """
 import ctypes
+import os
 
 import torch
 
@@ -298,7 +299,7 @@ def conv_out_hw(H, W, R, S, stride, pad):
 
 def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, res=None, res_mode=0,
                  want_stats=False, out_f32=False, out=None, accumulate=False, mode=0, out_hw=None,
-                 cin=None, x_geom=None, y_geom=None, cout_store=None, needs_grad=False, tag="", bnb=None):
+                 cin=None, x_geom=None, y_geom=None, cout_store=None, needs_grad=False, tag="", bnb=None, bn_fin=None):
     """Implicit-GEMM convolution.  x: Act.  w: compute-dtype tensor laid out [Cout][R][S][Cin].
 
     mode 0 = forward gather, mode 1 = dgrad gather (then ``out_hw`` is the input-gradient size and
@@ -349,13 +350,25 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         p.res_sB, p.res_sP = res.H * res.W * res.Cs, res.Cs
         p.res_H, p.res_W = res.H, res.W
     stats = None
+    keep = None
     if want_stats:
         tiles = call("mpn_conv_stats_tiles", ctypes.byref(p))
         stats = torch.empty((tiles, Cout, 2), dtype=torch.float32, device=dev)
         p.stats = stats.data_ptr()
+        if bn_fin is not None and tiles <= FIN_MAX_TILES:
+            # the last workgroup of every channel tile turns the tile partials into the BatchNorm coefficients (no finalize launch):
+            # the BNState comes back in the stats slot
+            gamma, beta, rm, rv, momentum, eps = bn_fin
+            keep, stats = stats, BNState(Cout, dev)
+            p.fin_counters = fin_counters(dev).data_ptr()
+            p.fin_gamma, p.fin_beta = gamma.data_ptr(), beta.data_ptr()
+            p.fin_rm = rm.data_ptr() if rm is not None else None
+            p.fin_rv = rv.data_ptr() if rv is not None else None
+            p.fin_out = stats.mean.data_ptr()
+            p.fin_count, p.fin_momentum, p.fin_eps = float(x.B * Ho * Wo), momentum, eps
     if bnb is not None:
         # this launch completes dz of a BatchNorm: its backward statistics ride in the epilogue (returned in the stats slot)
-        by, bz, st, relu = bnb
+        by, bz, st, relu = bnb[:4]
         assert y_geom is None and not out_f32 and by.t.shape == out.t.shape and by.t.dtype == out.t.dtype
         tiles = call("mpn_conv_stats_tiles", ctypes.byref(p))
         stats = torch.empty((tiles, Cout, 2), dtype=torch.float32, device=dev)
@@ -365,6 +378,19 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         p.bnb_mean, p.bnb_invstd = st.mean.data_ptr(), st.invstd.data_ptr()
         p.bnb_scale, p.bnb_shift = st.scale.data_ptr(), st.shift.data_ptr()
         p.bnb_relu = 1 if relu else 0
+        if len(bnb) > 4 and bnb[4] is not None and tiles <= FIN_MAX_TILES:
+            # ... and the last workgroup of every channel tile finishes the reduction: dgamma / dbeta and the (k1, k2, k3) of
+            # dy = k1*g + k2*y + k3 (mpn_bn_bwd_finalize's work); the coefficient tensor comes back in the stats slot
+            gamma, train, dgamma, dbeta = bnb[4]
+            keep, stats = stats, (torch.empty((3, Cout), dtype=torch.float32, device=dev) if train else None)
+            p.fin_counters = fin_counters(dev).data_ptr()
+            p.fin_gamma = gamma.data_ptr()
+            p.fin_out = stats.data_ptr() if stats is not None else None
+            p.fin_dgamma = dgamma.data_ptr() if dgamma is not None else None
+            p.fin_dbeta = dbeta.data_ptr() if dbeta is not None else None
+            p.fin_count, p.fin_train = float(x.B * Ho * Wo), 1 if train else 0
+            if stats is None:
+                stats = "frozen"
     if KERNEL_EVENTS.on:
         e0 = KERNEL_EVENTS.begin()
         call("mpn_conv_forward", ctypes.byref(p), stream_ptr())
@@ -470,6 +496,20 @@ def cast_lowp(src, dst):
 cast_bf16 = cast_lowp
 
 
+_fin_counters = {}
+# one workgroup per channel tile does the reduction: beyond this many pixel tiles the separate (wide) finalize launch is faster
+FIN_MAX_TILES = int(os.environ.get("MPN_BN_FIN_MAX_TILES", "64"))
+
+
+def fin_counters(device):
+    """Ticket counters of the in-launch BatchNorm finalize (mpn.h: fin_counters): zero between launches; shared by the launches
+    of one stream, which run one after another."""
+    t = _fin_counters.get(device)
+    if t is None:
+        t = _fin_counters[device] = torch.zeros(256, dtype=torch.int32, device=device)
+    return t
+
+
 class BNState(object):
     __slots__ = ("mean", "invstd", "scale", "shift")
 
@@ -502,7 +542,7 @@ def bn_act(y, st, relu, res=None, needs_grad=False, tag=""):
 
 
 def bn_backward(dz, z, y, st, gamma, relu, train, dgamma=None, dbeta=None, want_dy=True, dres=None, dres_acc=False, remask=False,
-                partial=None):
+                partial=None, coef=None):
     """Returns dy (Act or None).  dres (Act) receives/accumulates g = dz*(z>0).  remask=True (forward without a
     residual input): the ReLU mask is recomputed from y and the forward's scale/shift instead of reading z.
     partial: per-tile (sum g, sum g*xhat) already produced by the launch that wrote dz (conv_forward(bnb=...)); the
@@ -511,7 +551,12 @@ def bn_backward(dz, z, y, st, gamma, relu, train, dgamma=None, dbeta=None, want_
     P, C, Cs = y.P, y.C, y.Cs
     dc = dtype_code(y.t.dtype)
     k1, k2, k3 = st.scale, None, None        # frozen BN, no parameter gradients: dy = g * gamma * invstd
-    if train or dgamma is not None or dbeta is not None:
+    if coef is not None:
+        # reduction AND finalize already happened in the launch that completed dz (conv_forward(bnb=(..., fin))): dgamma / dbeta are
+        # in place, coef = [3][C] k1, k2, k3 (or "frozen": k1 = gamma * invstd = the forward scale)
+        if not isinstance(coef, str):
+            k1, k2, k3 = coef[0], coef[1], coef[2]
+    elif train or dgamma is not None or dbeta is not None:
         if partial is not None:
             part, chunks = partial, partial.shape[0]
         else:

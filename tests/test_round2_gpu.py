@@ -437,6 +437,57 @@ def test_bn_backward_statistics_in_the_dgrad_epilogue(dtype, mode):
     assert rel <= (2e-5 if dtype == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("dtype,mode", [(torch.bfloat16, "train"), (torch.float32, "train"), (torch.bfloat16, "frozen_affine")])
+def test_bn_finalize_inside_the_conv_launch(dtype, mode):
+    """The last workgroup to finish a channel tile reduces that tile's partial statistics and writes the BatchNorm coefficients
+    (MpnConvParams.fin_*): mpn_bn_finalize_train / mpn_bn_bwd_finalize launches disappear from the step.  Same step with the
+    in-launch finalize on and off: same loss, running statistics and gradients up to the rounding of one double reduction, and
+    the ticket counters are back at zero."""
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    from multiposenet.pytorch_amd import _lib
+    import multiposenet.pytorch_amd.ops as ops_mod
+    m, inputs, gts = _train_setup(101, dtype, 2, 160, seed=151)
+    if mode == "frozen_affine":
+        m.freeze_bn()
+    orig = _lib.call
+    calls = []
+
+    def counting(name, *a):
+        if name in ("mpn_bn_finalize_train", "mpn_bn_bwd_finalize"):
+            calls[-1] += 1
+        return orig(name, *a)
+    ops_mod.call = counting
+    res = []
+    bn0 = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
+    try:
+        for fused in (False, True):
+            calls.append(0)
+            m._engine.fuse_bn_finalize = fused
+            m.load_state_dict(bn0, strict=False)
+            m._arena.ensure_grads()
+            m._arena.grad_flat.zero_()
+            pred, saved = m(*inputs)
+            loss, log = poseNet.build_loss(saved, *gts)
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((loss.detach().clone(), m._arena.grad_flat.clone(),
+                        {k: v.clone() for k, v in m.state_dict().items() if "running_" in k}))
+    finally:
+        ops_mod.call = orig
+        m._engine.fuse_bn_finalize = True
+        m.train()
+    (l0, g0, r0), (l1, g1, r1) = res
+    assert int(ops_mod.fin_counters(g0.device).abs().sum()) == 0, "ticket counters not reset"
+    rel_l = abs(float(l0) - float(l1)) / abs(float(l0))
+    rel = float((g0 - g1).norm() / g0.norm())
+    rs = max(float((r0[k].float() - r1[k].float()).abs().max() / r0[k].float().abs().max().clamp_min(1e-12)) for k in r0)
+    report("BN finalize inside the conv launch (%s, %s): %d -> %d finalize launches; loss rel %.1e, gradient arena rel-L2 %.2e, "
+           "running statistics max rel %.1e" % (str(dtype), mode, calls[0], calls[1], rel_l, rel, rs))
+    assert calls[0] >= len(m._bns) and calls[1] <= 8
+    assert rel_l <= (1e-6 if dtype == torch.float32 else 1e-3) and rs <= 1e-5
+    assert rel <= (2e-5 if dtype == torch.float32 else 1e-2)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_folded_batchnorm_inference_equals_the_separate_passes(dtype):
     """Inference with frozen statistics folds BatchNorm (+ReLU, + the residual add of a Bottleneck, fpn.py:28-34) into the
