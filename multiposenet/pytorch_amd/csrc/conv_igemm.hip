@@ -367,14 +367,23 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
         unsigned pix = (unsigned)p0 + wp * C::WTP + ps * PASS_TILES * 16 + sp;
         unsigned b = (pix < P ? pix : 0u) / HoWo;
         unsigned rem = (pix < P ? pix : 0u) - b * HoWo;
+        // The store loop runs in groups of G iterations: every global load of a group (residual, accumulate, the BatchNorm operands)
+        // is in flight before the first result of the group is needed — one memory round trip per group instead of one per
+        // iteration (the accumulators are dead by now, their registers hold the loads).
+        constexpr int NIT = PASS_TILES * 16 / PPI;
+        constexpr int GMAX = 4;
+        constexpr int G = NIT < GMAX ? NIT : GMAX;
+        static_assert(NIT % G == 0, "store groups");
 #pragma unroll
-        for (int k = 0; k < PASS_TILES * 16 / PPI; ++k) {
-            if (pix < P && ccol < p.Cout_store && !(dbg & 128)) {
-                u32x4_t v = *reinterpret_cast<const u32x4_t*>(stage + (k * PPI + sp) * SROW + sc_ * 16);
-                OT* dst = Y + (long)b * p.y_sB + (long)rem * p.y_sP + ccol;
-                if (GENERAL && (p.res_mode != 0 || p.accumulate)) {
-                    // residual (same-size or nearest-upsampled source) and accumulate: 16-byte coalesced loads
-                    Vec16<OT> a; a.load(reinterpret_cast<const OT*>(&v));
+        for (int k0 = 0; k0 < NIT; k0 += G) {
+            bool live[G];
+            long yo[G];
+            u32x4_t l_res[G], l_acc[G], l_y[G], l_z[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                live[g] = pix < P && ccol < p.Cout_store && !(dbg & 128);
+                yo[g] = (long)b * p.y_sB + (long)rem * p.y_sP + ccol;
+                if (GENERAL && live[g]) {
                     if (p.res_mode != 0) {
                         long ro;
                         if (p.res_mode == 1) {
@@ -384,12 +393,31 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                             const unsigned rh = (ho * (unsigned)p.res_H) / (unsigned)p.Ho, rw = (wo * (unsigned)p.res_W) / (unsigned)p.Wo;
                             ro = (long)b * p.res_sB + (long)(rh * (unsigned)p.res_W + rw) * p.res_sP;
                         }
-                        Vec16<OT> r; r.load(Rz + ro + ccol);
+                        l_res[g] = *reinterpret_cast<const u32x4_t*>(Rz + ro + ccol);
+                    }
+                    if (p.accumulate) l_acc[g] = *reinterpret_cast<const u32x4_t*>(Y + yo[g]);
+                    if (bnb) {
+                        l_y[g] = *reinterpret_cast<const u32x4_t*>(Ybn + yo[g]);
+                        if (Zbn) l_z[g] = *reinterpret_cast<const u32x4_t*>(Zbn + yo[g]);
+                    }
+                }
+                pix += PPI; rem += PPI;
+                while (rem >= HoWo) { rem -= HoWo; ++b; }
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (!live[g]) continue;
+                u32x4_t v = *reinterpret_cast<const u32x4_t*>(stage + ((k0 + g) * PPI + sp) * SROW + sc_ * 16);
+                if (GENERAL && (p.res_mode != 0 || p.accumulate)) {
+                    // residual (same-size or nearest-upsampled source) and accumulate: 16-byte coalesced loads
+                    Vec16<OT> a; a.load(reinterpret_cast<const OT*>(&v));
+                    if (p.res_mode != 0) {
+                        Vec16<OT> r; r.load(reinterpret_cast<const OT*>(&l_res[g]));
 #pragma unroll
                         for (int e = 0; e < EV; ++e) a.v[e] += r.v[e];
                     }
                     if (p.accumulate) {
-                        Vec16<OT> r; r.load(dst);
+                        Vec16<OT> r; r.load(reinterpret_cast<const OT*>(&l_acc[g]));
 #pragma unroll
                         for (int e = 0; e < EV; ++e) a.v[e] += r.v[e];
                     }
@@ -399,27 +427,24 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                     }
                     a.store(reinterpret_cast<OT*>(&v));
                 }
-                *reinterpret_cast<u32x4_t*>(dst) = v;
+                *reinterpret_cast<u32x4_t*>(Y + yo[g]) = v;
                 if (bnb) {
-                    const long off = (long)b * p.y_sB + (long)rem * p.y_sP + ccol;
                     Vec16<OT> dzv, yy, zz;
                     dzv.load(reinterpret_cast<const OT*>(&v));                  // the value as stored
-                    yy.load(Ybn + off);
-                    if (Zbn) zz.load(Zbn + off);
+                    yy.load(reinterpret_cast<const OT*>(&l_y[g]));
+                    if (Zbn) zz.load(reinterpret_cast<const OT*>(&l_z[g]));
 #pragma unroll
                     for (int e = 0; e < EV; ++e) {
-                        float g = dzv.v[e];
+                        float gg = dzv.v[e];
                         if (pk.bnb_relu) {
                             const float zv = Zbn ? zz.v[e] : yy.v[e] * bsc[e] + bsf[e];
-                            if (!(zv > 0.f)) g = 0.f;
+                            if (!(zv > 0.f)) gg = 0.f;
                         }
-                        bs1[e] += g;
-                        bs2[e] += g * ((yy.v[e] - bmu[e]) * bis[e]);
+                        bs1[e] += gg;
+                        bs2[e] += gg * ((yy.v[e] - bmu[e]) * bis[e]);
                     }
                 }
             }
-            pix += PPI; rem += PPI;
-            while (rem >= HoWo) { rem -= HoWo; ++b; }
         }
         if (ps + 1 < NPASS) __syncthreads();
     }
