@@ -211,9 +211,31 @@ def build_names():
     return names
 
 
+def _check_heatmap_targets(preds, heat_temp, heat_weight):
+    """The kernels index the targets as pixel * 18 + channel with the pixel grid of the first prediction: anything the reference's
+    torch expression would broadcast (a [B,1,H,W] mask) is expanded here, anything it would reject raises before the launch."""
+    from .._lib import MpnError
+    p0 = preds[0]
+    B, _, H, W = p0.shape
+    for j, p in enumerate(preds):
+        if p.dim() != 4 or p.shape[0] != B or p.shape[2] != H or p.shape[3] != W or p.shape[1] < 18:
+            raise MpnError("heat-map loss: prediction %d has shape %s, expected [%d, >=18, %d, %d]" % (j, tuple(p.shape), B, H, W))
+        if p.device != p0.device:
+            raise MpnError("heat-map loss: predictions live on different devices")
+    out = []
+    for name, t in (("heat_temp", heat_temp), ("heat_weight", heat_weight)):
+        if t.dim() != 4 or t.shape[0] != B or t.shape[2] != H or t.shape[3] != W or t.shape[1] not in (1, 18):
+            raise MpnError("heat-map loss: %s has shape %s, expected [%d, 18, %d, %d]" % (name, tuple(t.shape), B, H, W))
+        if t.device != p0.device:
+            raise MpnError("heat-map loss: %s is on %s, the predictions on %s" % (name, t.device, p0.device))
+        out.append(t.expand(B, 18, H, W) if t.shape[1] == 1 else t)
+    return out
+
+
 def build_keypoint_loss(saved_for_loss, heat_temp, heat_weight):
     """posenet.py:367-403: returns (total_loss tensor with grad, OrderedDict of floats)."""
     names = build_names()
+    heat_temp, heat_weight = _check_heatmap_targets(saved_for_loss[:5], heat_temp, heat_weight)
     heat = ops.nchw_to_nhwc_f32(heat_temp.detach().float())
     wgt = ops.nchw_to_nhwc_f32(heat_weight.detach().float())
     total, out = _HeatmapMSE.apply(heat, wgt, *saved_for_loss[:5])

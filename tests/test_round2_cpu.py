@@ -97,3 +97,21 @@ def test_prn_rows_need_not_be_multiples_of_32():
     from multiposenet.pytorch_amd.network.posenet import poseNet
     m = poseNet(50, prn_node_count=64, prn_coeff=1)
     assert m.prn.dens1.weight.shape == (64, 28 * 18 * 17) and m.prn.dens2.weight.shape == (28 * 18 * 17, 64)
+
+
+def test_heatmap_loss_rejects_mismatched_targets_before_any_launch():
+    """the loss kernels index the targets with the prediction's pixel grid — wrong shapes must raise, a [B,1,H,W]
+    mask (which the reference's torch expression broadcasts, posenet.py:376-381) is expanded."""
+    import pytest
+    from multiposenet.pytorch_amd._lib import MpnError
+    from multiposenet.pytorch_amd.network.losses import _check_heatmap_targets
+    preds = [torch.zeros(2, 18, 8, 8) for _ in range(5)]
+    heat, wgt = torch.zeros(2, 18, 8, 8), torch.ones(2, 1, 8, 8)
+    h, w = _check_heatmap_targets(preds, heat, wgt)
+    assert tuple(w.shape) == (2, 18, 8, 8) and h is heat
+    with pytest.raises(MpnError):
+        _check_heatmap_targets(preds, torch.zeros(2, 18, 4, 4), wgt)
+    with pytest.raises(MpnError):
+        _check_heatmap_targets(preds, heat, torch.ones(2, 3, 8, 8))
+    with pytest.raises(MpnError):
+        _check_heatmap_targets(preds[:4] + [torch.zeros(2, 17, 8, 8)], heat, wgt)
