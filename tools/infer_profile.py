@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""cProfile of the post-processing stage of tools/infer_bench.py (heat-map peaks + PRN assignment), host side."""
+import cProfile
+import os
+import pstats
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.argv = [sys.argv[0], "--iters", "3"]
+import tools.infer_bench as ib      # noqa
+
+pr = cProfile.Profile()
+pr.enable()
+ib.main()
+pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
