@@ -26,15 +26,16 @@ _W9 = _W9 / _W9.sum()                 # scipy.ndimage._gaussian_kernel1d(sigma=1
 
 def _peaks_by_joint(kps):
     """tester.py:337-349: per joint type the list [x, y, 1, idx] with a running idx over (joint type, input order)."""
+    peaks = [[] for _ in range(17)]
+    for k in kps:                         # one pass in input order; the reference scans the list once per joint type
+        j = k[-1]
+        if j == int(j) and 0 <= j < 17:
+            peaks[int(j)].append([k[0], k[1], 1, 0])
     idx = 0
-    peaks = []
-    for j in range(17):
-        tl = []
-        for k in kps:
-            if k[-1] == j:
-                tl.append([k[0], k[1], 1, idx])
-                idx += 1
-        peaks.append(tl)
+    for tl in peaks:
+        for p in tl:
+            p[3] = idx
+            idx += 1
     return peaks
 
 
@@ -55,7 +56,7 @@ def prn_process_batch(model, kps_list, bbox_lists, file_names=None, image_ids=No
         offs = []
         for j in range(17):
             offs.append(len(flat_peaks))
-            flat_peaks.extend([p[0], p[1]] for p in peaks_all[i][j])
+            flat_peaks += [(p[0], p[1]) for p in peaks_all[i][j]]
         offs.append(len(flat_peaks))
         joint_off.append(offs)
         box_slices.append((len(flat_boxes), len(flat_boxes) + len(boxes_all[i])))

@@ -38,19 +38,24 @@ def _extract(heat_bjhw, thre1, upsamp, refine, cap):
     grow = cap is None                      # an explicit capacity is a hard limit (overflow raises)
     cap = DEFAULT_CAP if cap is None else cap
     pk, cnt = _peaks_device(heat_bjhw, thre1, upsamp, refine, cap)
-    if grow:
-        most = int(cnt.max().item()) if cnt.numel() else 0
-        if most > cap:
-            cap = 1 << (most - 1).bit_length()
-            pk, cnt = _peaks_device(heat_bjhw, thre1, upsamp, refine, cap)
-    return _split(pk, cnt, cap)
+    counts = cnt.cpu().numpy()              # the one host sync of the extraction
+    most = int(counts.max(initial=0))
+    if most > cap:
+        if not grow:
+            raise MpnError("more than %d peaks of one joint type in an image; raise `cap`" % cap)
+        cap = 1 << (most - 1).bit_length()
+        pk, cnt = _peaks_device(heat_bjhw, thre1, upsamp, refine, cap)
+        counts = cnt.cpu().numpy()
+    return _split(pk, counts, most)
 
 
-def _split(peaks, counts, cap):
-    peaks, counts = peaks.cpu().numpy(), counts.cpu().numpy()          # one D2H of the compact result
-    if int(counts.max(initial=0)) > cap:
-        raise MpnError("more than %d peaks of one joint type in an image; raise `cap`" % cap)
-    return [[peaks[b, j, :counts[b, j]].copy() for j in range(peaks.shape[1])] for b in range(peaks.shape[0])]
+def _split(peaks, counts, most):
+    """Only the occupied prefix [:, :, :most] of the peak buffer crosses PCIe."""
+    B, J = counts.shape
+    if most == 0:
+        return [[np.zeros((0, 4)) for _ in range(J)] for _ in range(B)]
+    host = peaks[:, :, :most].cpu().numpy()
+    return [[host[b, j, :counts[b, j]].copy() for j in range(J)] for b in range(B)]
 
 
 def find_peaks(param, img):

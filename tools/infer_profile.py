@@ -7,10 +7,12 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.argv = [sys.argv[0], "--iters", "3"]
-import tools.infer_bench as ib      # noqa
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import infer_bench as ib      # noqa
 
 pr = cProfile.Profile()
 pr.enable()
 ib.main()
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+st = pstats.Stats(pr).sort_stats("cumulative")
+st.print_stats("pytorch_amd|infer_bench|tolist|numpy|item|cpu|built-in", 60)
