@@ -52,8 +52,38 @@ def main():
         torch.cuda.synchronize()
         return float(loss)
 
-    red = ddp.attach(m, bucket_mb=8.0)
     k = B // world
+    if os.environ.get("MPN_DDP_MODE") == "replay":
+        # three optimizer steps of the data-parallel job, once through the eager step and once through the recorded launch list
+        # (collectives are part of the list): parameters must agree bit for bit, on every rank
+        import copy
+        from multiposenet.pytorch_amd.optim import FusedAdam
+        from multiposenet.pytorch_amd.replay import ReplayedTrainStep
+        from multiposenet.pytorch_amd.training.batch_processor import train_step
+        sl = slice(rank * k, (rank + 1) * k)
+        inputs = [[img[sl].contiguous(), "train_both"]]
+        gts = ["train_both", heat[sl].contiguous(), wgt[sl].contiguous(), anno[sl].contiguous()]
+        ddp.attach(m, bucket_mb=8.0)
+        start = copy.deepcopy(m.state_dict())
+        res = {}
+        for mode in ("eager", "replay"):
+            m.load_state_dict(start)
+            opt = FusedAdam(m, lr=1e-3, weight_decay=0.0)
+            stepper = ReplayedTrainStep(m, opt) if mode == "replay" else None
+            losses = []
+            for _ in range(4):
+                loss, _ = stepper(inputs, gts) if stepper is not None else train_step(m, opt, inputs, gts)
+                losses.append(float(loss))
+            torch.cuda.synchronize()
+            res[mode + "_params"] = m._arena.flat.detach().cpu().numpy().copy()
+            res[mode + "_loss"] = np.array(losses)
+            if stepper is not None:
+                res["replays"] = stepper.replays
+        np.savez(os.path.join(os.environ["MPN_DDP_OUT"], "rank%d.npz" % rank), backend=backend, **res)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    red = ddp.attach(m, bucket_mb=8.0)
     loss = step(m, slice(rank * k, (rank + 1) * k))
     grad = m._arena.grad_flat.cpu().numpy()
     lt = torch.tensor([loss], dtype=torch.float64)

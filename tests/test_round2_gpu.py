@@ -359,6 +359,30 @@ def test_two_rank_data_parallel_equals_global_batch_on_device():
     assert abs(float(res[0]["loss_mean"]) - float(res[0]["global_loss"])) <= 1e-5 * abs(float(res[0]["global_loss"]))
 
 
+def test_two_rank_recorded_step_equals_the_eager_data_parallel_step():
+    """The recorded launch list contains the reducer's collectives: four optimizer steps of a 2-rank job (1 eager + 1 recording +
+    2 replays) end with the same parameters, bit for bit, as four eager data-parallel steps — on both ranks."""
+    import socket
+    import tempfile
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = tempfile.mkdtemp(prefix="mpn_ddp2r_")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MPN_DDP_OUT=out, MPN_DDP_MODE="replay", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py")], env=dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, lg) in enumerate(zip(procs, logs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, lg[-3000:])
+    res = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(2)]
+    for r in range(2):
+        assert int(res[r]["replays"]) == 2
+        assert np.array_equal(res[r]["eager_params"], res[r]["replay_params"]), "rank %d: recorded step diverged from the eager step" % r
+        assert np.array_equal(res[r]["eager_loss"], res[r]["replay_loss"])
+    assert np.array_equal(res[0]["replay_params"], res[1]["replay_params"]), "ranks hold different parameters after four steps"
+    assert not np.array_equal(res[0]["eager_loss"], res[1]["eager_loss"]), "the two ranks should see different shards"
+    report("2-rank recorded step (%s): parameters bit-identical to the eager data-parallel job after 4 steps on both ranks"
+           % str(res[0]["backend"]))
+
+
 # ------------------------------------------------------------------------------------------------ pyramid towers
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_pyramid_towers_equal_the_per_level_launches(dtype):
