@@ -115,3 +115,25 @@ def test_heatmap_loss_rejects_mismatched_targets_before_any_launch():
         _check_heatmap_targets(preds, heat, torch.ones(2, 3, 8, 8))
     with pytest.raises(MpnError):
         _check_heatmap_targets(preds[:4] + [torch.zeros(2, 17, 8, 8)], heat, wgt)
+
+
+def test_opencv_resize_restatement_agrees_with_an_independent_implementation():
+    """cv2 is absent from this image, so the oracle's restatement of cv2.resize (joint_utils.py:110-113 peak refinement,
+    tester.py:264-331 scale pyramid) cannot be pinned to OpenCV itself.  Independent cross-check: torch's CPU interpolate uses the
+    same published rules (cubic convolution with a = -0.75, half-pixel centres, replicated border; bilinear likewise), written by
+    other people — the two agree to float32 rounding.  (Parity with cv2 proper stays UNPINNED; this rules out a wrong kernel, tap
+    offset or border rule.)"""
+    import torch.nn.functional as F
+    from oracle import joint_oracle as jo
+    rs = np.random.RandomState(0)
+    for f in (2.0, 4.0, 8.0):
+        for _ in range(4):
+            p = rs.rand(5, 5).astype(np.float32)
+            t = F.interpolate(torch.from_numpy(p)[None, None], scale_factor=f, mode='bicubic', align_corners=False)[0, 0].numpy()
+            assert np.abs(jo.cv_resize_cubic(p, f) - t).max() <= 1e-6
+    img = rs.rand(23, 31, 3).astype(np.float32)
+    chw = torch.from_numpy(img).permute(2, 0, 1)[None]
+    for hw in ((46, 62), (92, 124), (37, 55)):
+        for cubic, mode in ((True, 'bicubic'), (False, 'bilinear')):
+            t = F.interpolate(chw, size=hw, mode=mode, align_corners=False)[0].permute(1, 2, 0).numpy()
+            assert np.abs(jo.cv_resize(img, hw, cubic) - t).max() <= 1e-5
