@@ -2,6 +2,7 @@
 import copy
 import pickle
 
+import numpy as np
 import pytest
 import torch
 
