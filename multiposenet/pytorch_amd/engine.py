@@ -174,9 +174,10 @@ class Engine(object):
         kc = 32 if ops.is16(self.cdt) else 16
         rows, views, off, blk = [], {}, 0, 0
         stem = self.m.fpn.conv1.weight
-        for mod in self.m.modules():
+        prn_w = {id(q) for q in self.m.prn.parameters()}      # the PRN's Linear layers (71 M parameters) are not part of the
+        for mod in self.m.modules():                            # backbone / head passes: single transposes when the PRN trains
             w = getattr(mod, "weight", None)
-            if not isinstance(mod, (torch.nn.Conv2d, torch.nn.Linear)) or w is None or id(w) not in ar.index or w is stem:
+            if not isinstance(mod, (torch.nn.Conv2d, torch.nn.Linear)) or w is None or id(w) not in ar.index or w is stem or id(w) in prn_w:
                 continue
             if id(w) in views:
                 continue

@@ -244,7 +244,21 @@ class poseNet(nn.Module):
                 layer.eval()
 
     # ------------------------------------------------------------------ forward
-    def _prepare(self, img):
+    def _prn_split(self):
+        """Arena offset where the PRN's parameters start when they form the tail of the arena (they are registered last,
+        posenet.py:209), else None.  The PRN holds 71 of the 132 M parameters and is not part of the backbone / head passes."""
+        ar = self._arena
+        cached = getattr(ar, "_prn_split", False)
+        if cached is not False:
+            return cached
+        ids = [ar.index[id(q)] for q in self.prn.parameters() if id(q) in ar.index]
+        split = None
+        if ids and sorted(ids) == list(range(min(ids), len(ar.params))):
+            split = ar.offsets[min(ids)]
+        ar._prn_split = split
+        return split
+
+    def _prepare(self, img, prn=False):
         if not img.is_cuda:
             raise MpnError("poseNet runs on the MI355X only (input is on %s); there is no CPU path" % img.device)
         ops.check_device(img)
@@ -258,7 +272,13 @@ class poseNet(nn.Module):
             buf = ar.lowp.get(cdt)
             if buf is None:
                 buf = ar.lowp[cdt] = torch.empty(ar.total, dtype=cdt, device=ar.device)
-            ops.cast_lowp(ar.flat, buf)              # one launch refreshes every forward operand
+            split = self._prn_split()
+            if split is None:
+                ops.cast_lowp(ar.flat, buf)          # one launch refreshes every forward operand
+            elif prn:
+                ops.cast_lowp(ar.flat[split:], buf[split:])
+            elif split > 0:
+                ops.cast_lowp(ar.flat[:split], buf[:split])
         elif cdt != torch.float32:
             raise MpnError("compute_dtype must be torch.bfloat16, torch.float16 or torch.float32")
 
@@ -395,7 +415,7 @@ class poseNet(nn.Module):
         x = img_batch
         if not x.is_cuda:
             raise MpnError("poseNet runs on the MI355X only; there is no CPU path")
-        self._prepare(x)
+        self._prepare(x, prn=True)
         eng = self._engine
         prn = self.prn
         B = x.shape[0]
