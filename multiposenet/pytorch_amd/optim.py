@@ -100,7 +100,10 @@ class FusedAdam(torch.optim.Optimizer):
         ar = self.model._arena
         if ar is not None and ar.grad_flat is not None:
             if ar.grad_flat.is_cuda:
-                call("mpn_fill_f32", ops.ptr(ar.grad_flat), 0.0, ar.grad_flat.numel(), ops.stream_ptr())
+                # only trainable parameters ever receive gradients (frozen ones stay at the zeros they were allocated with)
+                runs = ar.trainable_runs()          # current requires_grad flags: a parameter unfrozen since the last step is included
+                for s, e in runs:
+                    call("mpn_fill_f32", ops.ptr(ar.grad_flat[s:e]), 0.0, e - s, ops.stream_ptr())
             else:
                 ar.grad_flat.zero_()
 
