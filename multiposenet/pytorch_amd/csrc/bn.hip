@@ -43,6 +43,31 @@ __device__ __forceinline__ void load_coef(const float* __restrict__ p, int c0, i
     }
 }
 
+// slice `sl` of 64: rows sl, sl+64, ... of the [n][C][2] partials of channel c, eight loads in flight (a dependent-load loop
+// costs a memory round trip per row: 4-15 round trips on the 225..900-tile layers), added in row order
+__device__ __forceinline__ void reduce_slices(const float* __restrict__ part, int n, int C, int c, int sl, double& s1, double& s2) {
+    const float* col = part + (long)c * 2;
+    const long stride = (long)C * 2;
+    int t = sl;
+    for (; t + 7 * 64 < n; t += 8 * 64) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2*>(col + (long)(t + u * 64) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
+    }
+    float2 w[8];
+    int m = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int tt = t + u * 64;
+        w[u] = tt < n ? *reinterpret_cast<const float2*>(col + (long)tt * stride) : make_float2(0.f, 0.f);
+        m += tt < n ? 1 : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (u < m) { s1 += (double)w[u].x; s2 += (double)w[u].y; }
+}
+
 // block = 4 channels x 64 tile-slices (the reduction over up to ~14k tiles is the only work: spread it wide)
 __global__ void bn_finalize_train_kernel(const float* __restrict__ stats, int tiles, int C, double count,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -53,12 +78,11 @@ __global__ void bn_finalize_train_kernel(const float* __restrict__ stats, int ti
     const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
     const int c = blockIdx.x * 4 + cl;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C) {
-        for (int t = sl; t < tiles; t += 64) {
-            const float2 v = *reinterpret_cast<const float2*>(stats + ((long)t * C + c) * 2);
-            s1 += (double)v.x; s2 += (double)v.y;
-        }
-    }
+    // per-channel parameters do not depend on the reduction: fetch them first so their latency hides behind it
+    const bool fin = sl == 0 && c < C;
+    const float g = (fin && gamma) ? gamma[c] : 1.f, b = (fin && beta) ? beta[c] : 0.f;
+    const float rm0 = (fin && rm) ? rm[c] : 0.f, rv0 = (fin && rv) ? rv[c] : 0.f;
+    if (c < C) reduce_slices(stats, tiles, C, c, sl, s1, s2);
     // the 16 slices a wave holds for each channel: xor-butterfly over lane bits 2..5, then 4 wave partials through LDS
 #pragma unroll
     for (int m = 4; m < 64; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
@@ -72,14 +96,13 @@ __global__ void bn_finalize_train_kernel(const float* __restrict__ stats, int ti
         double var = s2 / count - mu * mu;
         if (var < 0.0) var = 0.0;
         const float is = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
         mean[c] = (float)mu; invstd[c] = is;
         const float sc = g * is;
         scale[c] = sc; shift[c] = b - (float)mu * sc;
-        if (rm) rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mu;
+        if (rm) rm[c] = (1.f - momentum) * rm0 + momentum * (float)mu;
         if (rv) {
             const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-            rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unb;
+            rv[c] = (1.f - momentum) * rv0 + momentum * (float)unb;
         }
     }
 }
@@ -185,12 +208,10 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int ch
     const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
     const int c = blockIdx.x * 4 + cl;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C) {
-        for (int t = sl; t < chunks; t += 64) {
-            const float2 v = *reinterpret_cast<const float2*>(partial + ((long)t * C + c) * 2);
-            s1 += (double)v.x; s2 += (double)v.y;
-        }
-    }
+    const bool fin = sl == 0 && c < C;           // parameters first: their latency hides behind the reduction
+    const float is = fin ? invstd[c] : 0.f, gm = (fin && gamma) ? gamma[c] : 1.f, mu = fin ? mean[c] : 0.f;
+    const float db0 = (fin && dbeta) ? dbeta[c] : 0.f, dg0 = (fin && dgamma) ? dgamma[c] : 0.f;
+    if (c < C) reduce_slices(partial, chunks, C, c, sl, s1, s2);
 #pragma unroll
     for (int m = 4; m < 64; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -199,10 +220,9 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int ch
     if (sl == 0 && c < C) {
         s1 = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
         s2 = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
-        if (dbeta) dbeta[c] += (float)s1;
-        if (dgamma) dgamma[c] += (float)s2;
+        if (dbeta) dbeta[c] = db0 + (float)s1;
+        if (dgamma) dgamma[c] = dg0 + (float)s2;
         if (coef) {
-            const float is = invstd[c], gm = gamma ? gamma[c] : 1.f, mu = mean[c];
             const float a = (float)(s1 / count), b = (float)(s2 / count);
             coef[c] = gm * is;
             coef[C + c] = train ? -gm * is * is * b : 0.f;

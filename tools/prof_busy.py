@@ -10,7 +10,7 @@ skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
 cur = sqlite3.connect(db).cursor()
 rows = cur.execute("select start, end, name from kernels order by start").fetchall()
 # steady-state window: from the end of the 3rd optimizer launch to the end of the last one (whole steps only)
-adam = [r for r in rows if "adam_kernel" in r[2]]
+adam = [r for r in rows if "adam_dev_kernel" in r[2] or "adam_kernel" in r[2]]
 if len(adam) >= 5:
     lo, hi = adam[2][1], adam[-1][1]
     nsteps = len(adam) - 3
