@@ -237,7 +237,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
     constexpr int LPP = C::WTC * OSZ / 16;                    // lanes per pixel in the store phase
     constexpr int PPI = 64 / LPP;                             // pixels per store instruction
     constexpr int EV = 16 / OSZ;                              // elements per 16-byte store
-    static_assert(4 * REGION <= C::NST * C::STAGE_BYTES, "staging area must fit the main-loop LDS");
+    static_assert(4 * REGION + C::WAVES_P * TC * 8 <= C::NST * C::STAGE_BYTES, "staging area + statistics scratch must fit the main-loop LDS");
     const unsigned HoWo = (unsigned)p.Ho * (unsigned)p.Wo;
     const unsigned P = (unsigned)p.B * HoWo;           // launcher guarantees P < 2^31
     OT* __restrict__ Y = (OT*)p.y;
@@ -288,9 +288,11 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
         }
     }
 
-    if (p.stats && !(dbg & 64)) {
-        // per-channel (sum, sum^2) of the stored values: over this lane's MP pixels, then over the 16 pixel
-        // lanes of the DPP row, then over the WAVES_P waves via LDS
+    // ---- BatchNorm tile statistics: per-channel (sum, sum^2) of the stored values: over this lane's MP pixels, then over the 16
+    // pixel lanes of the DPP row, then over the WAVES_P waves via LDS scratch `sf`.  The plain kernels run this AFTER the stores were
+    // issued (the reductions overlap the tile's drain to HBM; scratch behind the staging area, so no barrier against its readers);
+    // the general kernels before them (the accumulators must be dead while the grouped epilogue loads hold their registers).
+    auto tile_stats = [&](float* sf) {
         float pm[C::MP];
 #pragma unroll
         for (int j = 0; j < C::MP; ++j) pm[j] = (((unsigned)p0 + wp * C::WTP + j * 16 + lcol) < P) ? 1.f : 0.f;
@@ -308,7 +310,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                 q = row16_sum(q);
                 if (lcol == 0) {
                     const int row = wc * C::WTC + i * 16 + lrow4 + c;      // 0..TC-1
-                    *reinterpret_cast<float2*>(lds_f + (wp * TC + row) * 2) = make_float2(a, q);
+                    *reinterpret_cast<float2*>(sf + (wp * TC + row) * 2) = make_float2(a, q);
                 }
             }
         __syncthreads();
@@ -319,12 +321,15 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                 float a = 0.f, q = 0.f;
 #pragma unroll
                 for (int w = 0; w < C::WAVES_P; ++w) {
-                    a += lds_f[(w * TC + t) * 2 + 0];
-                    q += lds_f[(w * TC + t) * 2 + 1];
+                    a += sf[(w * TC + t) * 2 + 0];
+                    q += sf[(w * TC + t) * 2 + 1];
                 }
                 store_partial(p.stats + ((long)tp * p.Cout + cout) * 2, a, q, pk.fin_counters != nullptr);
             }
         }
+    };
+    if (GENERAL && p.stats && !(dbg & 64)) {
+        tile_stats(lds_f);
         __syncthreads();
     }
 
@@ -448,6 +453,8 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
         }
         if (ps + 1 < NPASS) __syncthreads();
     }
+    if (!GENERAL && p.stats && !(dbg & 64)) tile_stats(reinterpret_cast<float*>(lds + 4 * REGION));
+
     if (bnb) {
         // lanes sharing a channel chunk (same sc_, different pixel slot sp): butterfly over the sp bits
 #pragma unroll
