@@ -9,10 +9,9 @@ run() {
   echo "$tag $ms" | tee -a $O/sweep.txt
 }
 run base X=1
-run bn8192 MPN_BN_BLOCKS=8192
+run fin0 MPN_BN_FUSED_FINALIZE=0
 run base X=1
-run bn8192 MPN_BN_BLOCKS=8192
-run bn32768 MPN_BN_BLOCKS=32768
-run bn6144 MPN_BN_BLOCKS=6144
+run fin0 MPN_BN_FUSED_FINALIZE=0
+run fin128 MPN_BN_FIN_MAX_TILES=128
+run fin32 MPN_BN_FIN_MAX_TILES=32
 run base X=1
-run bn8192 MPN_BN_BLOCKS=8192
