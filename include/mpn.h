@@ -106,6 +106,9 @@ typedef struct MpnConvParams {
 int mpn_conv_stats_tiles(const MpnConvParams* p);
 /* output-channel rows of the tile (256 / 128 / 64 / 32) the launcher will pick: names the kernel instantiation */
 int mpn_conv_tile_rows(const MpnConvParams* p);
+/* 1 when the launcher will take conv_igemm_s3_kernel (3x3, stride 1, pad 1, 16-bit operands, dense input: the pixel tile of a kernel
+ * row lands once and serves its three taps), 0 for conv_igemm_kernel: names the kernel instantiation */
+int mpn_conv_shared_tile(const MpnConvParams* p);
 int mpn_conv_forward(const MpnConvParams* p, void* stream);
 
 typedef struct MpnWgradParams {

@@ -73,6 +73,7 @@ SIGNATURES = {
     "mpn_prn_scores": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mpn_conv_stats_tiles": (_i, [_PC]),
     "mpn_conv_tile_rows": (_i, [_PC]),
+    "mpn_conv_shared_tile": (_i, [_PC]),
     "mpn_conv_forward": (_i, [_PC, _vp]),
     "mpn_conv_wgrad_chunks": (_i, [_PW]),
     "mpn_conv_wgrad_seg_plan": (_i, [_PW]),
@@ -145,7 +146,7 @@ SIGNATURES = {
 }
 
 # entry points that return a count, not a status
-_COUNT_FUNCS = {"mpn_conv_stats_tiles", "mpn_conv_tile_rows", "mpn_conv_wgrad_chunks", "mpn_conv_wgrad_seg_plan", "mpn_conv_wgrad_kernel_id", "mpn_bn_bwd_chunks", "mpn_channel_sum_chunks",
+_COUNT_FUNCS = {"mpn_conv_stats_tiles", "mpn_conv_tile_rows", "mpn_conv_shared_tile", "mpn_conv_wgrad_chunks", "mpn_conv_wgrad_seg_plan", "mpn_conv_wgrad_kernel_id", "mpn_bn_bwd_chunks", "mpn_channel_sum_chunks",
                 "mpn_mse_chunks", "mpn_focal_blocks", "mpn_bce_chunks", "mpn_nms_workspace_bytes", "mpn_nms_batched_workspace_bytes", "mpn_version"}
 
 _lib = None

@@ -667,6 +667,192 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_kernel(const
     else        conv_epilogue<T, T, TC, TP, GENERAL>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
 }
 
+// 3x3 / stride 1 / pad 1 variant (forward and stride-1 dgrad), 16-bit types: the k-loop is bound by operand delivery (global -> LDS
+// DMA at ~45 of the CU's 64 B/clk), and the three horizontal taps of a kernel row read the SAME pixels shifted by one.  The
+// pixel tile of a (kernel row r, channel chunk) group therefore lands ONCE, as TP + 2 rows (pixels p0-1 .. p0+TP of the row r input
+// line; padded to 192 DMA rows), and the taps s = 0..2 read it at row offsets 0 / 1 / 2.  What the shared rows cannot encode — the
+// left / right image border, which depends on the OUTPUT pixel's column — is a per-lane select on the fragments of the two outer
+// taps; the vertical border is a property of the row itself (every consumer of a row sits in the same output line) and stays a
+// DMA-time zero fill.  Per group: 3 weight tiles + 1 pixel tile instead of 3 + 3 (-31 % DMA bytes, -25 % DMA instructions).
+// k order: (r, channel chunk, s).  LDS: weight ring 3 x A_BYTES, pixel ring 2 x 12 KB (same total as the generic kernel).
+template <typename T, int TC, int TP, bool OUTF32, bool GENERAL>
+__global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(const MpnConvParams pk, const int dbg) {
+    using C = ConvCfg<T, TC, TP>;
+    static_assert(sizeof(T) == 2 && TP == 128, "16-bit operands, 128-pixel tiles");
+    constexpr int B_ROWS = 192, B_BYTES = B_ROWS * 64, LB = 3, LA = C::A_PER_W;
+    constexpr int A_RING = 3 * C::A_BYTES;
+    static_assert(A_RING + 2 * B_BYTES == C::NST * C::STAGE_BYTES, "same LDS footprint as the generic kernel");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[A_RING + 2 * B_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave / C::WAVES_P, wp = wave % C::WAVES_P;
+    const int tilesC = (pk.Cout_store + TC - 1) / TC;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int tp = bid / tilesC;
+    const int tc = bid - tp * tilesC;
+    MpnConvParams p = pk;
+    if (pk.nseg > 0) {
+        int l = 0;
+#pragma unroll
+        for (int k = 1; k < MPN_MAX_SEG; ++k) l += (k < pk.nseg && tp >= pk.seg_tile0[k]) ? 1 : 0;
+        l = __builtin_amdgcn_readfirstlane(l);
+        tp -= pk.seg_tile0[l];
+        p.x = pk.seg_x[l]; p.y = pk.seg_y[l];
+        p.H = p.Ho = pk.seg_H[l]; p.W = p.Wo = pk.seg_W[l];
+        p.x_sH = (int64_t)p.W * pk.x_sW; p.x_sB = (int64_t)p.H * p.x_sH;
+        p.y_sB = (int64_t)p.H * p.W * pk.y_sP;
+    }
+    const unsigned HoWo = (unsigned)p.Ho * (unsigned)p.Wo;
+    const unsigned P = (unsigned)p.B * HoWo;
+    const long p0 = (long)tp * TP;
+    const int c0 = tc * TC;
+    constexpr unsigned TS = 2u;
+    const long KW = 9L * p.Cin;
+    const unsigned x_bytes = (unsigned)((long)p.B * p.x_sB * TS);
+    const unsigned w_bytes = (unsigned)((long)p.Cout * KW * TS);
+    const i32x4_t rsrc_x = make_rsrc(p.x, x_bytes);
+    const i32x4_t rsrc_w = make_rsrc(p.w, w_bytes);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
+
+    const int u_row = lane >> 2;
+    const int u_piece = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
+    unsigned a_voff[LA];
+#pragma unroll
+    for (int q = 0; q < LA; ++q) {
+        const int row = ((int)wave_u * LA + q) * 16 + u_row;
+        const int cout = c0 + row;
+        const bool ok = (row < TC) && (cout < p.Cout);
+        a_voff[q] = ok ? (unsigned)(((long)cout * KW + u_piece * C::V) * TS) : w_bytes;
+    }
+    // pixel-tile DMA units: LDS row i holds input pixel (linear index) p0 - 1 + i of the line the current kernel row selects
+    unsigned b_base[LB];
+    int b_h[LB];
+    bool b_ok[LB];
+#pragma unroll
+    for (int q = 0; q < LB; ++q) {
+        const int i = ((int)wave_u * LB + q) * 16 + u_row;
+        const long pc = p0 - 1 + i;
+        const bool ok = i < TP + 2 && pc >= 0 && pc < (long)P;
+        const unsigned pcu = ok ? (unsigned)pc : 0u;
+        const unsigned rem = pcu % HoWo;
+        b_h[q] = (int)(rem / (unsigned)p.Wo);
+        b_ok[q] = ok;
+        b_base[q] = (unsigned)(((long)pcu * p.x_sW + u_piece * C::V) * TS);
+    }
+    const int line_b = (int)(p.W * p.x_sW * TS);                  // bytes between two image lines
+
+    f32x4_t acc[C::MC][C::MP];
+#pragma unroll
+    for (int i = 0; i < C::MC; ++i)
+#pragma unroll
+        for (int j = 0; j < C::MP; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // fragment gather.  Weights: as in the generic kernel.  Pixels: fragment j, lane -> tile row  l + 1 + dx  (l = local pixel index,
+    // dx = -1 / 0 / +1 the tap's column shift), un-swizzled with that ROW's key.
+    const int f_off = (lane & 15) * 64 + (((lane >> 4) ^ ((0 - ((lane >> 2) & 3)) & 3)) * 16);
+    const int fa_off = wc * C::WTC * 64 + f_off;
+    int fb_off[3][C::MP];
+    unsigned edge_l = 0u, edge_r = 0u;                            // bit j: the lane's pixel of fragment j sits in the first / last column
+#pragma unroll
+    for (int j = 0; j < C::MP; ++j) {
+        const int l = wp * C::WTP + j * 16 + (lane & 15);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int row = l + d;
+            fb_off[d][j] = row * 64 + (((lane >> 4) ^ ((0 - (row >> 2)) & 3)) * 16);
+        }
+        const unsigned pix = (unsigned)p0 + (unsigned)l;
+        const unsigned wo = (pix < P ? pix : 0u) % (unsigned)p.Wo;
+        edge_l |= (wo == 0u ? 1u : 0u) << j;
+        edge_r |= (wo == (unsigned)p.Wo - 1u ? 1u : 0u) << j;
+    }
+
+    const int chunks = p.Cin / C::KC;
+    const int groups = 3 * chunks;                                // (r, channel chunk) groups of three taps
+    // issue state: the next weight tile to queue is tap (ar, as_) of chunk acc_; the next pixel tile is group (br, bcc)
+    int ar = 0, acc_ = 0, as_ = 0, br = 0, bcc = 0;
+    auto issue_a = [&](unsigned slot) {
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((ar * 3 + as_) * p.Cin + acc_) * TS));
+        const unsigned st = lds_base + slot * C::A_BYTES;
+#pragma unroll
+        for (int q = 0; q < LA; ++q)
+            lds_dma16(a_voff[q], rsrc_w, so, __builtin_amdgcn_readfirstlane(st + (wave_u * LA + q) * 1024u));
+        if (++as_ == 3) { as_ = 0; acc_ += C::KC; if (acc_ == p.Cin) { acc_ = 0; ++ar; } }
+    };
+    auto issue_b = [&](unsigned slot) {
+        const int dy = (p.mode == 0) ? br - 1 : 1 - br;           // input line relative to the output line
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)bcc * TS));
+        const unsigned st = lds_base + A_RING + slot * B_BYTES;
+#pragma unroll
+        for (int q = 0; q < LB; ++q) {
+            const bool ok = b_ok[q] && (unsigned)(b_h[q] + dy) < (unsigned)p.H;
+            const unsigned voff = ok ? (unsigned)((int)b_base[q] + dy * line_b) : x_bytes;
+            lds_dma16(voff, rsrc_x, so, __builtin_amdgcn_readfirstlane(st + (wave_u * LB + q) * 1024u));
+        }
+        bcc += C::KC;
+        if (bcc == p.Cin) { bcc = 0; ++br; }
+    };
+    auto compute = [&](unsigned aslot, unsigned bslot, int s) {
+        const int dx = (p.mode == 0) ? s : 2 - s;                 // tile row offset 0 / 1 / 2  <=>  column shift -1 / 0 / +1
+        const unsigned char* abase = lds + aslot * C::A_BYTES;
+        const unsigned char* bbase = lds + A_RING + bslot * B_BYTES;
+        u32x4_t fa[C::MC], fb[C::MP];
+#pragma unroll
+        for (int i = 0; i < C::MC; ++i)
+            fa[i] = *reinterpret_cast<const u32x4_t*>(abase + fa_off + i * 1024);
+#pragma unroll
+        for (int j = 0; j < C::MP; ++j) {
+            const int off = dx == 0 ? fb_off[0][j] : (dx == 1 ? fb_off[1][j] : fb_off[2][j]);
+            fb[j] = *reinterpret_cast<const u32x4_t*>(bbase + off);
+        }
+        if (dx != 1) {                                           // outer taps: pixels beyond the left / right border read zeros
+            const unsigned edge = dx == 0 ? edge_l : edge_r;
+#pragma unroll
+            for (int j = 0; j < C::MP; ++j)
+                if ((edge >> j) & 1u) fb[j] = (u32x4_t){0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < C::MC; ++i)
+#pragma unroll
+            for (int j = 0; j < C::MP; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+    };
+
+    // prologue: pixel tile of group 0, weight tiles of its first two taps
+    issue_b(0u);
+    issue_a(0u);
+    issue_a(1u);
+    unsigned acur = 0u, anxt = 2u;
+    for (int g = 0; g < groups; ++g) {
+        const unsigned bcur = (unsigned)(g & 1);
+        const bool last = g + 1 == groups;
+        // tap 0: needs weights (g,0) and pixel tile g; younger in flight: weights (g,1)
+        if (last) wait_vmcnt<0>(); else wait_vmcnt<LA>();
+        __builtin_amdgcn_s_barrier();
+        if (!last) issue_b(bcur ^ 1u);                            // pixel tile of the next group (its slot was last read one step ago)
+        issue_a(anxt);                                            // weights (g,2)
+        compute(acur, bcur, 0);
+        acur = (acur == 2u) ? 0u : acur + 1u; anxt = (anxt == 2u) ? 0u : anxt + 1u;
+        // tap 1: needs weights (g,1); younger: pixel tile g+1 and weights (g,2)
+        if (last) wait_vmcnt<0>(); else wait_vmcnt<LB + LA>();
+        __builtin_amdgcn_s_barrier();
+        if (!last) issue_a(anxt);                                 // weights (g+1,0)
+        compute(acur, bcur, 1);
+        acur = (acur == 2u) ? 0u : acur + 1u; anxt = (anxt == 2u) ? 0u : anxt + 1u;
+        // tap 2: needs weights (g,2); younger: weights (g+1,0)
+        if (last) wait_vmcnt<0>(); else wait_vmcnt<LA>();
+        __builtin_amdgcn_s_barrier();
+        if (!last) issue_a(anxt);                                 // weights (g+1,1)
+        compute(acur, bcur, 2);
+        acur = (acur == 2u) ? 0u : acur + 1u; anxt = (anxt == 2u) ? 0u : anxt + 1u;
+    }
+    __syncthreads();
+
+    const int ntiles = (int)(gridDim.x / (unsigned)tilesC);
+    if (OUTF32) conv_epilogue<T, float, TC, TP, GENERAL>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
+    else        conv_epilogue<T, T, TC, TP, GENERAL>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
+}
+
 constexpr int kTP = 128;
 
 // Block tile height (output channels).  The k-loop is bound by the DMA/LDS path, so the tallest tile that still
@@ -685,8 +871,23 @@ inline int pick_tc(const MpnConvParams& p, long tilesP) {
     return blocks128 >= min_blocks ? 128 : 64;
 }
 
+inline bool conv_uses_s3(const MpnConvParams& p, int tc) {
+    static const bool on = !(getenv("MPN_IGEMM_S3") && atoi(getenv("MPN_IGEMM_S3")) == 0);
+    if (!on || p.dtype == MPN_F32 || p.R != 3 || p.S != 3 || p.stride != 1 || p.pad != 1 || tc < 64) return false;
+    if (p.nseg > 0) return true;                                  // pyramid levels are dense by construction
+    return p.H == p.Ho && p.W == p.Wo && p.x_sH == (int64_t)p.W * p.x_sW && p.x_sB == (int64_t)p.H * p.x_sH;
+}
+
 template <typename T, bool OUTF32, bool GENERAL>
 int launch_conv_k(const MpnConvParams& p, int tc, long grid, int dbg, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        if (conv_uses_s3(p, tc)) {
+            if (tc == 256) hipLaunchKernelGGL((conv_igemm_s3_kernel<T, 256, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+            else if (tc == 128) hipLaunchKernelGGL((conv_igemm_s3_kernel<T, 128, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+            else hipLaunchKernelGGL((conv_igemm_s3_kernel<T, 64, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+            return mpn_launch_status();
+        }
+    }
     if (tc == 256) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
     else if (tc == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
     else if (tc == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
@@ -720,6 +921,12 @@ extern "C" int mpn_conv_tile_rows(const MpnConvParams* p) {
     if (!p) return MPN_E_BADARG;
     const long P = (long)p->B * p->Ho * p->Wo;
     return pick_tc(*p, p->nseg > 0 ? (long)p->seg_tile0[p->nseg] : (P + kTP - 1) / kTP);
+}
+
+extern "C" int mpn_conv_shared_tile(const MpnConvParams* p) {
+    if (!p) return MPN_E_BADARG;
+    const long P = (long)p->B * p->Ho * p->Wo;
+    return conv_uses_s3(*p, pick_tc(*p, p->nseg > 0 ? (long)p->seg_tile0[p->nseg] : (P + kTP - 1) / kTP)) ? 1 : 0;
 }
 
 extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {

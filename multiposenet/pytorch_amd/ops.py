@@ -240,7 +240,7 @@ def conv_forward_seg(xs, w, Cout, R, S, pad, bias=None, act=0, out_f32=False, mo
         call("mpn_conv_forward", ctypes.byref(p), stream_ptr())
         tc = call("mpn_conv_tile_rows", ctypes.byref(p))
         general = (bias is not None or accumulate or act != 0 or Cout % tc != 0)
-        name = "conv_igemm_kernel<%s, %d, 128, %s, %s>" % (dtype_name(dt), tc, "true" if p.out_f32 else "false", "true" if general else "false")
+        name = ("conv_igemm_s3_kernel" if call("mpn_conv_shared_tile", ctypes.byref(p)) == 1 else "conv_igemm_kernel") + "<%s, %d, 128, %s, %s>" % (dtype_name(dt), tc, "true" if p.out_f32 else "false", "true" if general else "false")
         if KERNEL_EVENTS.detail:
             name = "%s %dx%d %d->%d pyramid(%s)|0" % ("dgrad" if mode == 1 else "fwd", R, S, p.Cin, Cout, ",".join(str(x.H) for x in xs))
         KERNEL_EVENTS.end(name, sum(2.0 * x.B * x.H * x.W * Cout * R * S * min(p.Cin, x.C) for x in xs), e0)
@@ -400,7 +400,7 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         flops = 2.0 * x.B * Ho * Wo * Cout * live * min(Cin, x.C if x_geom is None else Cin)
         # the name rocprofv3 prints for this instantiation (tools/rocprof_summary.py spelling)
         general = (scale is not None or bias is not None or res is not None or accumulate or act != 0 or Cout % tc != 0 or bnb is not None)
-        name = "conv_igemm_kernel<%s, %d, 128, %s, %s>" % (dtype_name(dt), tc,
+        name = ("conv_igemm_s3_kernel" if call("mpn_conv_shared_tile", ctypes.byref(p)) == 1 else "conv_igemm_kernel") + "<%s, %d, 128, %s, %s>" % (dtype_name(dt), tc,
                                                           "true" if p.out_f32 else "false", "true" if general else "false")
         if KERNEL_EVENTS.detail:
             es = 2 if is16(dt) else 4

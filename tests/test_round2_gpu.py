@@ -534,3 +534,39 @@ def test_folded_batchnorm_inference_equals_the_separate_passes(dtype):
         rel = float((a - b).norm() / b.norm())
         report("folded BN (%s) %s: rel-L2 vs separate passes %.2e" % (str(dtype), name, rel))
         assert rel <= lim
+
+
+# ------------------------------------------------------------------------------------------------ shared pixel tile of the 3x3 kernel
+@pytest.mark.parametrize("geom", [(3, 4, 4, 64, 64), (2, 8, 8, 256, 128), (2, 15, 15, 64, 256), (1, 30, 30, 128, 128), (2, 17, 33, 64, 64),
+                                  (1, 60, 60, 64, 64), (32, 30, 30, 256, 256)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_3x3_kernel_with_shared_pixel_tile_is_exact_at_the_borders(geom, mode):
+    """conv_igemm_s3_kernel lands the pixel tile of a kernel row once and reads it at three column shifts; the image's left / right
+    border is a per-lane select, the top / bottom border a DMA-time zero fill.  bf16 operands, fp32 output (no output rounding):
+    against torch's fp32 convolution of the same bf16-rounded operands the result may differ by accumulation order only — any
+    border slip would be an O(1) error.  Forward and stride-1 dgrad, tiles that span several image lines (W = 4, 8, 15), lines
+    that span tiles (W = 33, 60), images that end inside a tile, the 256-row tile (last case)."""
+    import torch.nn.functional as F
+    from multiposenet.pytorch_amd import ops
+    from helpers import from_act, rnd, rng_normal, to_act, w_krsc
+    B, H, W, Cin, Cout = geom
+    dt = torch.bfloat16
+    x = rnd(dt, rng_normal(31, B, Cin, H, W))
+    w = rnd(dt, rng_normal(32, Cout, Cin, 3, 3) / (Cin * 9) ** 0.5)
+    if mode == 0:
+        ref = F.conv2d(x, w, None, stride=1, padding=1)
+        out, _ = ops.conv_forward(to_act(x, dt), w_krsc(w, dt), Cout, 3, 3, 1, 1, out_f32=True)
+    else:
+        dy = rnd(dt, rng_normal(33, B, Cout, H, W))
+        ref = F.conv_transpose2d(dy, w, None, stride=1, padding=1)          # = dgrad of the forward convolution
+        kc = 32
+        cout_pad = (Cout + kc - 1) // kc * kc
+        wm = w.permute(0, 2, 3, 1).contiguous().cuda()
+        wt = torch.empty((Cin, 3, 3, cout_pad), dtype=dt, device="cuda")
+        ops.weight_transpose(wm, wt, Cout, 9, Cin, cout_pad)
+        out, _ = ops.conv_forward(to_act(dy, dt), wt, Cin, 3, 3, 1, 1, mode=1, out_hw=(H, W), cin=cout_pad, out_f32=True)
+    torch.cuda.synchronize()
+    got = from_act(out).float()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    report("3x3 shared-pixel-tile kernel %s mode %d: max err / max |ref| = %.2e" % (str(geom), mode, err))
+    assert err <= 2e-5
