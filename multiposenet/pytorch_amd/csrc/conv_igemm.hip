@@ -20,6 +20,8 @@
 //     (sum, sum^2) partials BatchNorm needs in train mode.
 // dgrad reuses the kernel with mode=1 (transposed gather hi = (ho + pad - r)/stride) and the
 // [Cin][R][S][Cout_pad] weight copy made by mpn_weight_transpose.
+// 3x3 / stride 1 / pad 1 launches with 16-bit operands take conv_igemm_s3_kernel (below): same tile, ring and epilogue, but the pixel
+// tile of a kernel row lands once for its three taps (the k-loop is bound by operand delivery, not by MFMA issue).
 #include "common.h"
 #include <stdlib.h>
 
