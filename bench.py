@@ -10,6 +10,10 @@ arena overlapped with backward); weak scaling (32 images per GPU).
     python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        # no launcher: re-executes itself under torch.distributed.run with N ranks
+
+`n_gpus` in the result always equals --gpus: a launcher whose WORLD_SIZE disagrees, or fewer visible devices than ranks, is an
+error (exit status 3, no JSON line), never a silently smaller job.
 
 The timed step is the recorded step of multiposenet/pytorch_amd/replay.py (forward, losses, zero_grad, backward on two
 HIP streams, RCCL buckets, Adam — recorded once as a launch list and re-issued per step (replay.py); `--launch graph`
@@ -177,12 +181,39 @@ def pmc_traffic(kernel_class):
         return None, None
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here (one process per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1) — the same command line the driver uses for N > 1.  Never returns."""
+    import socket
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to run a smaller job under that label\n"
+                         % (args.gpus, ndev))
+        sys.exit(3)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver (RCCL needs it)
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args)
         return
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; n_gpus would mislabel the run\n" % (args.gpus, world))
+        sys.exit(3)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # stdout carries exactly one JSON line: RCCL prints a version banner to fd 1 when its first communicator comes up,
@@ -191,6 +222,9 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if torch.cuda.device_count() <= local:
+        sys.stderr.write("bench.py: rank %d wants cuda:%d but only %d GPU(s) are visible\n" % (rank, local, torch.cuda.device_count()))
+        sys.exit(3)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         import torch.distributed as dist
