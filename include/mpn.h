@@ -369,9 +369,10 @@ int mpn_heatmap_peaks(const float* heat, int64_t sB, int64_t sJ, int64_t sY, int
 
 /* cv2.resize for float32 images / heat-map stacks (evaluate/tester.py:67,213,296-299): src element (y, x, c) at
  * src[y*sY + x*sX + c*sC]; dst dense [Hd][Wd][C]; cubic != 0 -> INTER_CUBIC, else INTER_LINEAR (OpenCV's coordinate rule
- * (d + 0.5)*scale - 0.5, clamped taps, horizontal then vertical pass, float32). */
+ * (d + 0.5)*scale - 0.5, clamped taps, horizontal then vertical pass, float32).  scale = src/dst (the dsize call form) unless
+ * inv_fy / inv_fx > 0: those are 1/fy, 1/fx of the `cv2.resize(img, None, fx=, fy=)` form (tester.py:68), used as the scale exactly. */
 int mpn_resize(const float* src, int64_t sY, int64_t sX, int64_t sC, int Hs, int Ws, int C, float* dst, int Hd, int Wd,
-               int cubic, void* stream);
+               int cubic, double inv_fy, double inv_fx, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pose-residual-network person assignment, device half (evaluate/tester.py:333-513; crop/gaussian helpers

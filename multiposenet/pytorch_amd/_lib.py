@@ -68,7 +68,7 @@ _PW = ctypes.POINTER(WgradParams)
 SIGNATURES = {
     "mpn_gt_heatmaps": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, ctypes.c_double, ctypes.c_double, _vp]),
     "mpn_heatmap_peaks": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _f, ctypes.c_double, _i, _vp, _vp, _i, _vp]),
-    "mpn_resize": (_i, [_vp, _i64, _i64, _i64, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "mpn_resize": (_i, [_vp, _i64, _i64, _i64, _i, _i, _i, _vp, _i, _i, _i, ctypes.c_double, ctypes.c_double, _vp]),
     "mpn_prn_build_maps": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, ctypes.c_double, _vp, _vp, _vp, _vp, _vp]),
     "mpn_prn_scores": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mpn_conv_stats_tiles": (_i, [_PC]),

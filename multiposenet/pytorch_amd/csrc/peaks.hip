@@ -144,13 +144,14 @@ __global__ void __launch_bounds__(PK_THREADS) heatmap_peaks_kernel(const float* 
 // four clamped taps per axis) or INTER_LINEAR (two taps; source coordinate clamped as OpenCV does), horizontal pass then
 // vertical pass, float32, left-to-right sums.  One thread per destination element.
 __global__ void resize_kernel(const float* __restrict__ src, long sY, long sX, long sC, int Hs, int Ws, int C,
-                              float* __restrict__ dst, int Hd, int Wd, int cubic) {
+                              float* __restrict__ dst, int Hd, int Wd, int cubic, double inv_fy, double inv_fx) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)Hd * Wd * C) return;
     const int c = (int)(i % C);
     const int dx = (int)((i / C) % Wd);
     const int dy = (int)(i / ((long)C * Wd));
-    const double scale_x = (double)Ws / (double)Wd, scale_y = (double)Hs / (double)Hd;
+    // dsize form: scale = src / dst; fx / fy form (cv2.resize(img, None, fx=, fy=)): scale = 1 / f exactly
+    const double scale_x = inv_fx > 0.0 ? inv_fx : (double)Ws / (double)Wd, scale_y = inv_fy > 0.0 ? inv_fy : (double)Hs / (double)Hd;
     auto at = [&](int y, int x) { return src[(long)y * sY + (long)x * sX + (long)c * sC]; };
     if (cubic) {
         int yi[4], xi[4]; float yc[4], xc[4];
@@ -212,11 +213,11 @@ extern "C" int mpn_heatmap_peaks(const float* heat, int64_t sB, int64_t sJ, int6
 }
 
 extern "C" int mpn_resize(const float* src, int64_t sY, int64_t sX, int64_t sC, int Hs, int Ws, int C, float* dst, int Hd, int Wd,
-                          int cubic, void* stream) {
-    MPN_CHECK_ARG(src && dst && Hs > 0 && Ws > 0 && C > 0 && Hd > 0 && Wd > 0);
+                          int cubic, double inv_fy, double inv_fx, void* stream) {
+    MPN_CHECK_ARG(src && dst && Hs > 0 && Ws > 0 && C > 0 && Hd > 0 && Wd > 0 && inv_fy >= 0.0 && inv_fx >= 0.0);
     const long n = (long)Hd * Wd * C;
     MPN_CHECK_ARG(n < 0x7fffffffL * 256L);
     hipLaunchKernelGGL(resize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (long)sY, (long)sX, (long)sC,
-                       Hs, Ws, C, dst, Hd, Wd, cubic);
+                       Hs, Ws, C, dst, Hd, Wd, cubic, inv_fy, inv_fx);
     return mpn_launch_status();
 }

@@ -50,12 +50,15 @@ class TestParams(object):
     print_freq = 20
 
 
-def resize(img, out_hw, cubic):
-    """cv2.resize(img, (out_w, out_h), interpolation=INTER_CUBIC if cubic else INTER_LINEAR) for a CUDA float32 [H, W, C] tensor."""
+def resize(img, out_hw, cubic, inv_scale=None):
+    """cv2.resize(img, (out_w, out_h), interpolation=INTER_CUBIC if cubic else INTER_LINEAR) for a CUDA float32 [H, W, C] tensor.
+    ``inv_scale=(1/fy, 1/fx)`` selects OpenCV's ``fx/fy`` call form (``cv2.resize(img, None, fx=, fy=)``), which maps destination
+    to source coordinates with exactly 1/f instead of src/dst (they differ whenever round(src * f) != src * f)."""
     H, W, C = img.shape
     Hd, Wd = int(out_hw[0]), int(out_hw[1])
     out = torch.empty((Hd, Wd, C), dtype=torch.float32, device=img.device)
-    call("mpn_resize", ops.ptr(img), img.stride(0), img.stride(1), img.stride(2), H, W, C, ops.ptr(out), Hd, Wd, 1 if cubic else 0, ops.stream_ptr())
+    sy, sx = (0.0, 0.0) if inv_scale is None else (float(inv_scale[0]), float(inv_scale[1]))
+    call("mpn_resize", ops.ptr(img), img.stride(0), img.stride(1), img.stride(2), H, W, C, ops.ptr(out), Hd, Wd, 1 if cubic else 0, sy, sx, ops.stream_ptr())
     return out
 
 
@@ -70,7 +73,7 @@ def crop_with_factor(im, dest_size, factor=32, pad_val=0, basedon='min'):
     base = {'min': min(h0, w0), 'max': max(h0, w0), 'w': w0, 'h': h0}.get(basedon, min(h0, w0))
     im_scale = float(dest_size) / base
     h, w = _round_half_even(h0 * im_scale), _round_half_even(w0 * im_scale)       # dsize = round(src * f)
-    scaled = resize(im, (h, w), cubic=False)
+    scaled = resize(im, (h, w), cubic=False, inv_scale=(1.0 / im_scale, 1.0 / im_scale))       # cv2.resize(im, None, fx=s, fy=s), tester.py:68
     new_h, new_w = int(np.ceil(float(h) / factor)) * factor, int(np.ceil(float(w) / factor)) * factor
     padded = torch.full((new_h, new_w, im.shape[2]), float(pad_val), dtype=torch.float32, device=im.device)
     padded[:h, :w] = scaled
@@ -112,6 +115,45 @@ class Tester(object):
 
     def _load_ckpt(self, ckpt):
         _, _ = net_utils.load_net(ckpt, self.model, load_state_dict=True)
+
+    # ------------------------------------------------------------------ validation loss (Tester.val, tester.py:515-543)
+    def val(self):
+        """Loss of ``params.subnet_name`` over ALL of ``val_data`` in eval mode with frozen statistics: every batch goes through
+        ``batch_processor`` -> forward -> ``build_loss``; a log block every ``print_freq`` batches.  The reference only logs the
+        result; here ``(mean, std)`` of the per-batch losses is returned as well.  Log values are fetched asynchronously
+        (losses.LazyFloat) and read when a block is printed, so the loop never waits for the device in between."""
+        from ..training.trainer import LogBook, RunningStat, Stopwatch, _scalar_proxy
+        if self.val_data is None or self.batch_processor is None:
+            raise ValueError('Tester.val() needs the val_data and batch_processor given to the constructor')
+        self.model.eval()
+        book, seen = LogBook(), RunningStat()
+        batch_timer, data_timer = Stopwatch(), Stopwatch()
+        logger.info('Val on validation set...')
+        n = len(self.val_data)
+        batch_timer.start()
+        data_timer.start()
+        with torch.no_grad():
+            for step, batch in enumerate(self.val_data):
+                data_timer.lap()
+                inputs, gts, _ = self.batch_processor(self, batch)
+                _, saved_for_loss = self.model(*inputs)
+                batch_timer.lap()
+                loss, log = self.model.build_loss(saved_for_loss, *gts)
+                seen.add(_scalar_proxy(loss, True))
+                book.record(log)
+                if step % self.params.print_freq == 0:
+                    text = '{}\n{}: epoch {}[{}/{}]'.format(self.params.exp_name, 'Validation', 0, step, n) + ''.join(book.lines())
+                    text += '\n\t({:.2f}/{:.2f}s, fps:{:.1f})'.format(data_timer.mean + 1e-6, batch_timer.mean + 1e-6,
+                                                                     self.params.batch_size / (batch_timer.mean + 1e-6))
+                    logger.info(text)
+                    batch_timer.clear()
+                    data_timer.clear()
+                data_timer.start()
+                batch_timer.start()
+        mean, std = seen.value()
+        logger.info('\n\nValidation loss: mean: {}, std: {}'.format(mean, std))
+        self.last_val_log = book
+        return mean, std
 
     # ------------------------------------------------------------------ shared pieces
     def _boxes(self, scores, classification, transformed_anchors, scale):
@@ -173,7 +215,7 @@ class Tester(object):
     def _get_outputs(self, multiplier, img):
         """tester.py:264-313: heat-maps of every scale resized back to the image and averaged; boxes per scale."""
         H, W = img.shape[0], img.shape[1]
-        heatmap_avg = torch.zeros((H, W, 18), dtype=torch.float32, device=self.dev)
+        heatmap_avg = torch.zeros((H, W, 18), dtype=torch.float64, device=self.dev)       # np.zeros(...) accumulator: float64 (tester.py:266)
         bbox_all = []
         for scale in multiplier:
             inp_size = scale * H

@@ -1,18 +1,23 @@
-"""Checkpoint I/O with the reference's interface and file layout (``network/net_utils.py:12-110``):
+"""Checkpoint files in the reference's on-disk format, on top of the built-in HDF5 codec (``hdf5min``).
+
+What a checkpoint IS is fixed by the reference (``network/net_utils.py:30-110``) and pinned by tests/golden/g14_trainer.json
+(recorded from the real functions) and g11_*.h5 (written by the real h5py):
+
+  ``<name>.h5``                      one little-endian dataset per ``state_dict()`` entry under its flat key, logical shapes
+                                     ([Cout, Cin, R, S] for convolutions, whatever the arena stores), root attribute ``epoch``;
+  ``<name>.h5.optimizer_state.pk``   pickle of ``[optimizer.state_dict(), ...]`` with every tensor on the CPU.
+
+How it is done here is this stack's own: the parameter arena crosses PCIe as ONE transfer instead of one per tensor, files
+appear atomically (written beside the target, then renamed), pruning tolerates another process having removed a file first,
+and loading resolves names through an index of the file built once.  Entry points keep the reference's names / signatures:
 
     save_net(fname, net, epoch=-1, optimizers=None, rm_prev_opt=False, max_n_ckpts=-1)
-    epoch, lr_or_state_dicts = load_net(fname, net, prefix='', load_state_dict=False)
-
-A checkpoint is one flat HDF5 file — a dataset per ``net.state_dict()`` key (fp32 / int64 numpy arrays in the
-reference's logical [Cout, Cin, R, S] layout, whatever the arena stores physically) plus the root attribute ``epoch`` —
-and, when optimizers are given, ``fname + '.optimizer_state.pk'``: a pickle of ``[optimizer.state_dict(), ...]`` with
-the tensors moved to the CPU.  h5py is used when it can be imported; otherwise the built-in ``hdf5min`` module reads
-and writes the same bytes-on-disk subset, so the authors' ``ckpt_baseline_resnet101.h5`` loads either way.
+    load_net(fname, net, prefix='', load_state_dict=False) -> (epoch, learning_rates | optimizer state dicts | None)
+    set_optimizer_state_devices(state, device_id=None)
 """
 import logging
 import os
 import pickle
-from copy import deepcopy
 
 import numpy as np
 import torch
@@ -22,114 +27,149 @@ from . import hdf5min
 
 logger = logging.getLogger("multiposenet")
 
-try:                                    # pragma: no cover  (not installed in the build image)
-    import h5py as _h5py
-except ImportError:
-    _h5py = None
+OPT_SUFFIX = '.optimizer_state.pk'
+
+
+# ---------------------------------------------------------------------------------------------------- small helpers
+def _moved(obj, device):
+    """Copy of a nested optimizer-state structure with every tensor on `device` (containers rebuilt, leaves shared)."""
+    if torch.is_tensor(obj):
+        return obj.detach().to(device)
+    if isinstance(obj, dict):
+        return type(obj)((k, _moved(v, device)) for k, v in obj.items())
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_moved(v, device) for v in obj)
+    return obj
 
 
 def set_optimizer_state_devices(state, device_id=None):
-    """net_utils.py:12-27: move optimizer state tensors to the CPU (device_id None) or to cuda:device_id."""
-    for k, v in state.items():
-        for k2 in v.keys():
-            if hasattr(v[k2], 'cuda'):
-                if device_id is None:
-                    v[k2] = v[k2].cpu()
-                else:
-                    v[k2] = v[k2].cuda(device_id)
+    """``optimizer.state`` (or the 'state' part of a state dict) moved IN PLACE: to the CPU when ``device_id`` is None, else
+    to ``cuda:device_id``; entries that are not tensors stay as they are.  Returns ``state`` (net_utils.py:12-27)."""
+    target = torch.device('cpu') if device_id is None else torch.device('cuda', int(device_id))
+    for slot in state.values():
+        for name in list(slot.keys()):
+            if torch.is_tensor(slot[name]):
+                slot[name] = slot[name].to(target)
     return state
 
 
-def _write_h5(fname, arrays, epoch):
-    if _h5py is not None:
-        with _h5py.File(fname, mode='w') as h5f:
-            for k, v in arrays:
-                h5f.create_dataset(k, data=v)
-            h5f.attrs['epoch'] = epoch
-    else:
-        hdf5min.write_file(fname, arrays, attrs={'epoch': np.int64(epoch)})
+def checkpoint_index(name):
+    """Trailing integer of a checkpoint's stem ('ckpt_12.h5' -> 12): the order checkpoints are aged by."""
+    stem = os.path.splitext(name)[0]
+    return int(stem.split('_')[-1])
 
 
-def _open_h5(fname):
-    if _h5py is not None:
-        return _h5py.File(fname, mode='r')
-    return hdf5min.File(fname)
+def list_checkpoints(folder):
+    """``*.h5`` files of `folder`, oldest first.  ('.h5.best' / '.h5.ckpt' copies carry another extension and never count.)"""
+    names = [n for n in os.listdir(folder or '.') if os.path.splitext(n)[-1] == '.h5']
+    return sorted(names, key=checkpoint_index)
 
 
+def _unlink(path):
+    try:
+        os.remove(path)
+        logger.info('Remove {}'.format(path))
+    except FileNotFoundError:            # another rank / process was faster
+        pass
+
+
+def _host_state(net):
+    """[(key, numpy array)] of ``net.state_dict()``.  A network whose parameters live in a flat arena (poseNet) is fetched
+    with a single device-to-host copy of the arena; the per-key arrays are host views in the logical layout."""
+    sd = net.state_dict()
+    arena = getattr(net, '_arena', None)
+    host = {}
+    if arena is not None and arena.flat.is_cuda and arena.consistent():
+        flat = arena.flat.detach().cpu()
+        by_ptr = {p.data_ptr(): i for i, p in enumerate(arena.params)}
+        for k, v in sd.items():
+            i = by_ptr.get(v.data_ptr())
+            if i is not None and tuple(arena.params[i].shape) == tuple(v.shape):
+                host[k] = arena._view(flat, i, v.shape)
+    out = []
+    for k, v in sd.items():
+        t = host.get(k)
+        if t is None:
+            t = v.detach().cpu()
+        a = t.numpy()
+        out.append((k, a if a.flags.c_contiguous else a.copy(order='C')))      # (np.ascontiguousarray would turn 0-d into 1-d)
+    return out
+
+
+def _write_atomically(path, writer):
+    tmp = '%s.tmp%d~' % (path, os.getpid())
+    try:
+        writer(tmp)
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
+# ---------------------------------------------------------------------------------------------------- save
 def save_net(fname, net, epoch=-1, optimizers=None, rm_prev_opt=False, max_n_ckpts=-1):
-    """net_utils.py:30-66."""
-    arrays = [(k, v.detach().cpu().contiguous().numpy()) for k, v in net.state_dict().items()]
-    _write_h5(fname, arrays, epoch)
+    """Write ``fname`` (+ the optimizer pickle when ``optimizers`` is given).  Only with optimizers: ``rm_prev_opt`` deletes
+    every OTHER ``*.optimizer_state.pk`` of the folder, ``max_n_ckpts > 0`` keeps the newest that many ``*.h5`` files."""
+    arrays = _host_state(net)
+    _write_atomically(fname, lambda p: hdf5min.write_file(p, arrays, attrs={'epoch': np.int64(epoch)}))
+    if optimizers is None:
+        return
+    folder = os.path.split(fname)[0]
+    state_file = fname + OPT_SUFFIX
+    payload = [_moved(opt.state_dict(), torch.device('cpu')) for opt in optimizers]
 
-    if optimizers is not None:
-        state_dicts = []
-        for optimizer in optimizers:
-            state_dict = deepcopy(optimizer.state_dict())
-            state_dict['state'] = set_optimizer_state_devices(state_dict['state'], device_id=None)
-            state_dicts.append(state_dict)
-        state_file = fname + '.optimizer_state.pk'
-        with open(state_file, 'wb') as f:
-            pickle.dump(state_dicts, f)
+    def dump(p):
+        with open(p, 'wb') as f:
+            pickle.dump(payload, f)
+    _write_atomically(state_file, dump)
+    if rm_prev_opt:
+        for n in os.listdir(folder or '.'):
+            p = os.path.join(folder, n)
+            if n.endswith(OPT_SUFFIX) and p != state_file:
+                _unlink(p)
+    if max_n_ckpts > 0:
+        names = list_checkpoints(folder)
+        for n in names[:max(0, len(names) - max_n_ckpts)]:
+            _unlink(os.path.join(folder, n))
 
-        if rm_prev_opt:                                  # keep only the newest optimizer state (net_utils.py:49-55)
-            root = os.path.split(fname)[0]
-            for filename in os.listdir(root or '.'):
-                filename = os.path.join(root, filename)
-                if filename.endswith('.optimizer_state.pk') and filename != state_file:
-                    logger.info('Remove {}'.format(filename))
-                    os.remove(filename)
 
-        if max_n_ckpts > 0:                              # prune old checkpoints by their trailing index (net_utils.py:58-66)
-            root = os.path.split(fname)[0]
-            ckpts = [f for f in os.listdir(root or '.') if os.path.splitext(f)[-1] == '.h5']
-            ckpts = sorted(ckpts, key=lambda name: int(os.path.splitext(name)[0].split('_')[-1]))
-            if len(ckpts) > max_n_ckpts:
-                for ckpt in ckpts[0:-max_n_ckpts]:
-                    filename = os.path.join(root, ckpt)
-                    logger.info('Remove {}'.format(filename))
-                    os.remove(filename)
+# ---------------------------------------------------------------------------------------------------- load
+def _is_data_parallel_file(names):
+    """True when every stored name carries the 'module.' prefix nn.DataParallel adds."""
+    return all(str(n).startswith('module.') for n in names)
 
 
 def load_net(fname, net, prefix='', load_state_dict=False):
-    """net_utils.py:69-110: copies every matching dataset into ``net.state_dict()`` in place; tolerates a 'module.'
-    prefix on the stored names (files saved from nn.DataParallel), missing layers and shape mismatches (warnings)."""
-    with _open_h5(fname) as h5f:
-        h5f_is_module = True
-        for k in h5f.keys():
-            if not str(k).startswith('module.'):
-                h5f_is_module = False
-                break
-        if prefix == '' and not isinstance(net, nn.DataParallel) and h5f_is_module:
+    """Copy the stored tensors into ``net.state_dict()`` in place.  A file saved from a DataParallel-wrapped model loads into
+    a bare one; a name the file lacks or a tensor of another shape is reported with a warning and skipped.
+    Returns ``(epoch, x)``: epoch is -1 when the file has no such attribute; x is the array of learning rates stored in the
+    file's attributes (``learning_rates``, or ``[lr]`` when ``lr`` > 0, else empty) or, with ``load_state_dict=True``, the
+    list unpickled from ``fname + '.optimizer_state.pk'`` (None if that file does not exist)."""
+    with hdf5min.File(fname) as h5f:
+        stored = set(h5f.keys())
+        if prefix == '' and not isinstance(net, nn.DataParallel) and _is_data_parallel_file(stored):
             prefix = 'module.'
-
-        for k, v in net.state_dict().items():
-            k = prefix + k
-            if k in h5f:
-                param = torch.from_numpy(np.asarray(h5f[k]))
-                if v.size() != param.size():
-                    logger.warning('Inconsistent shape: {}, {}'.format(v.size(), param.size()))
-                else:
-                    v.copy_(param)
-            else:
-                logger.warning('No layer: {}'.format(k))
-
-        epoch = h5f.attrs['epoch'] if 'epoch' in h5f.attrs else -1
-        epoch = int(epoch)
-
+        with torch.no_grad():
+            for key, dst in net.state_dict().items():
+                name = prefix + key
+                if name not in stored:
+                    logger.warning('No layer: {}'.format(name))
+                    continue
+                src = torch.from_numpy(np.asarray(h5f[name]))
+                if tuple(src.shape) != tuple(dst.shape):
+                    logger.warning('Inconsistent shape: {}, {}'.format(tuple(dst.shape), tuple(src.shape)))
+                    continue
+                dst.copy_(src)
+        attrs = h5f.attrs
+        epoch = int(attrs['epoch']) if 'epoch' in attrs else -1
         if not load_state_dict:
-            if 'learning_rates' in h5f.attrs:
-                lr = h5f.attrs['learning_rates']
-            else:
-                lr = h5f.attrs.get('lr', -1)
-                lr = np.asarray([lr] if lr > 0 else [], dtype=float)          # np.float (net_utils.py:98) is gone in numpy 2
-            return epoch, lr
-
-    state_file = fname + '.optimizer_state.pk'
-    if os.path.isfile(state_file):
-        with open(state_file, 'rb') as f:
-            state_dicts = pickle.load(f)
-            if not isinstance(state_dicts, list):
-                state_dicts = [state_dicts]
-    else:
-        state_dicts = None
-    return epoch, state_dicts
+            if 'learning_rates' in attrs:
+                return epoch, np.asarray(attrs['learning_rates'], dtype=float)
+            lr = float(attrs.get('lr', -1))
+            return epoch, np.asarray([lr] if lr > 0 else [], dtype=float)
+    state_file = fname + OPT_SUFFIX
+    if not os.path.isfile(state_file):
+        return epoch, None
+    with open(state_file, 'rb') as f:
+        state_dicts = pickle.load(f)
+    return epoch, state_dicts if isinstance(state_dicts, list) else [state_dicts]

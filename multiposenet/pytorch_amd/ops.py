@@ -502,11 +502,13 @@ FIN_MAX_TILES = int(os.environ.get("MPN_BN_FIN_MAX_TILES", "64"))
 
 
 def fin_counters(device):
-    """Ticket counters of the in-launch BatchNorm finalize (mpn.h: fin_counters): zero between launches; shared by the launches
-    of one stream, which run one after another."""
-    t = _fin_counters.get(device)
+    """Ticket counters of the in-launch BatchNorm finalize (mpn.h: fin_counters): zero between launches.  One buffer per
+    (device, launch stream): launches of one stream run one after another, launches of different streams (a second model or a
+    Tester beside training) must not draw tickets from the same counters."""
+    key = (device, stream_handle() if device.type == "cuda" else 0)
+    t = _fin_counters.get(key)
     if t is None:
-        t = _fin_counters[device] = torch.zeros(256, dtype=torch.int32, device=device)
+        t = _fin_counters[key] = torch.zeros(256, dtype=torch.int32, device=device)
     return t
 
 

@@ -130,6 +130,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     def state_dict(self):
         ar = self.model._arena
+        if self._m is not None and self._arena is not ar and ar is not None:
+            self._bind()                     # the arena was rebuilt since the last step (model.to(...)): carry the moments over first
         groups, k = [], 0
         for g in self.param_groups:
             d = {key: val for key, val in g.items() if key != "params"}

@@ -124,6 +124,12 @@ class ReplayedTrainStep(object):
             from .training.batch_processor import train_step
             return train_step(self.model, self.opt, inputs, gts)
         ops.check_device(img)
+        # The recorded launches read the input tensors IN PLACE; a conversion (.float() / .contiguous()) inside the body would be
+        # a torch op that is not on the list, and replays would keep reading the first batch's converted copy.
+        for name, tsr in [("image batch", img)] + [("target %d" % i, g) for i, g in enumerate(tensors)]:
+            if tsr.dtype != torch.float32 or not tsr.is_contiguous():
+                raise _lib.MpnError("recorded train step: %s must be a contiguous float32 tensor (got %s, contiguous=%s); convert it in "
+                                    "the data pipeline or use training.batch_processor.train_step" % (name, tsr.dtype, tsr.is_contiguous()))
         key = (subnet, tuple(img.shape), img.dtype, tuple((tuple(t.shape), t.dtype) for t in tensors))
         ent = self._entries.get(key)
         if ent is not None and ent.sig != self._state_sig():

@@ -1,290 +1,459 @@
-"""Trainer — the reference's training harness (``training/trainer.py:22-380``) over the MI355X path.
+"""Training driver for the MI355X path behind the reference's ``Trainer`` interface.
 
-Same construction and behaviour as the reference:
+Only the INTERFACE comes from the reference (``training/trainer.py:44-105`` option names, ``:116`` constructor,
+``:176`` ``train()``); its behaviour — which epochs write ``ckpt_{epoch}.h5``, when the validation pass runs and which
+checkpoint becomes ``ckpt_{epoch}_{loss:.5f}.h5.best``, how the two scheduler families are stepped, what a resume restores
+under ``re_init`` / ``zero_epoch`` / ``ignore_opt_state``, the BatchNorm mode rules around validation — is pinned by
+``tests/golden/g14_trainer.json``, recorded from the real class (tests/golden/make_golden_trainer.py), not transcribed.
 
-    trainer = Trainer(model, train_params, batch_processor, train_data, val_data)
-    trainer.train()
+What is built differently, for one process per GPU and a device that runs a step in 40 ms:
 
-  * ``TrainParams`` carries the reference's fields (:44-103);
-  * per epoch: ``_LRScheduler.step(epoch)`` before the epoch, ``_train_one_epoch`` (:233-283: batch_processor -> forward ->
-    build_loss -> zero_grad -> backward -> optional gradient clipping -> step, meters, the ``fps`` log line every
-    ``print_freq`` steps, step checkpoints), checkpoint ``ckpt_{epoch}.h5`` every ``save_freq_epoch`` epochs (+ pruning),
-    validation over ``val_nbatch_end_epoch`` batches in eval mode with ``freeze_bn`` re-applied afterwards unless the
-    subnet is the keypoint one (:285-320), a copy ``ckpt_{epoch}_{loss:.5f}.h5.best`` when the validation loss improves and
-    ``ReduceLROnPlateau.step(val_loss)`` (:176-217);
-  * resume: the newest ``ckpt_*.h5`` of ``save_dir`` (or ``params.ckpt``) restores weights, epoch and optimizer state (:160-175,
-    :224-231).
-Differences, all forced by the platform: one process per GPU instead of ``ListDataParallel`` (the model goes to
-``cuda:gpus[0]``; when ``torch.distributed`` is initialised the gradient reducer of ddp.py is attached and
-``batch_size`` is the per-rank batch), log values may be ``numbers.Real`` proxies (losses.set_lazy_log), and
-``params.use_graph`` replays the step as a captured hipGraph (graph.py) — off by default.
+  * **the step** is the recorded launch list (``replay.ReplayedTrainStep``): forward, losses, both backward streams, gradient
+    buckets and FusedAdam are re-issued from one list (host cost 5 ms instead of 19); the eager tape is used when the optimizer
+    is not ``FusedAdam``, the subnet is the PRN, or gradient clipping needs the norms on the host;
+  * **no per-step host sync**: the loss and the log values are fetched with asynchronous copies (``losses.LazyFloat``) and
+    only become floats when a log line is formatted (every ``print_freq`` steps) — the reference reads ``loss.item()``
+    and seven more ``.item()`` values per step;
+  * **data parallelism** is ``torch.distributed`` with the gradient reducer of ``ddp.py`` instead of ``ListDataParallel``
+    (datasets/data_parallel.py:16-87): every rank runs this class on its shard; rank 0 alone writes, prunes and copies
+    checkpoints (the others wait at a barrier), and the validation loss is averaged over ranks before it decides the best
+    checkpoint and steps ``ReduceLROnPlateau``, so all replicas take the same decisions;
+  * a resumed stock ``torch.optim`` optimizer gets its moments moved next to the parameters (the reference's
+    ``set_optimizer_state_devices`` call, trainer.py:229).
 """
 import datetime
 import logging
+import math
 import numbers
 import os
 import shutil
 import sys
+import time
 from collections import OrderedDict
 
-import numpy as np
 import torch
-import torch.nn as nn
-from torch.optim.lr_scheduler import ReduceLROnPlateau
+import torch.distributed as dist
+from torch.optim.lr_scheduler import LRScheduler, ReduceLROnPlateau
 from torch.optim.optimizer import Optimizer
 
-try:                                        # torch >= 2.0 names the base class LRScheduler
-    from torch.optim.lr_scheduler import LRScheduler as _LRScheduler
-except ImportError:                          # pragma: no cover
-    from torch.optim.lr_scheduler import _LRScheduler
-
-from ..lib.utils.meter import AverageValueMeter
-from ..lib.utils.timer import Timer
 from ..network import net_utils
 
 logger = logging.getLogger("multiposenet")
 
+INF = float('inf')
 
-def get_learning_rates(optimizer):
-    return np.asarray([pg['lr'] for pg in optimizer.param_groups], dtype=float)
+# option name -> default: the reference's TrainParams fields in their order (trainer.py:44-80), then this stack's additions
+_OPTIONS = OrderedDict([
+    ('exp_name', 'experiment_name'), ('subnet_name', 'keypoint_subnet'), ('batch_size', 32), ('max_epoch', 30), ('optimizer', None),
+    ('lr_scheduler', None), ('max_grad_norm', INF),
+    ('gpus', [0]), ('save_dir', None),
+    ('ckpt', None), ('re_init', False), ('zero_epoch', False), ('ignore_opt_state', False),
+    ('save_freq_epoch', 1), ('save_freq_step', sys.maxsize), ('save_nckpt_max', sys.maxsize),
+    ('val_freq', 500), ('val_nbatch', 10), ('val_nbatch_end_epoch', 200),
+    ('print_freq', 20), ('use_tensorboard', False), ('visualization_fn', None),
+])
+_EXTRA_OPTIONS = OrderedDict([
+    ('launch', 'replay'),        # 'replay' (recorded launch list) | 'graph' (captured hipGraph) | 'eager' (Python tape)
+    ('lazy_log', True),          # log values / loss fetched asynchronously, materialised when a line is printed
+])
 
 
 class TrainParams(object):
-    # required params (trainer.py:45-50)
-    exp_name = 'experiment_name'
-    subnet_name = 'keypoint_subnet'
-    batch_size = 32
-    max_epoch = 30
-    optimizer = None
-    # learning rate scheduler
-    lr_scheduler = None         # ReduceLROnPlateau or an LRScheduler
-    max_grad_norm = np.inf
-    # local environment
-    gpus = [0]
-    save_dir = None             # default: outputs/{exp_name}
-    # loading an existing checkpoint
-    ckpt = None                 # path; None = the newest ckpt in save_dir
-    re_init = False
-    zero_epoch = False
-    ignore_opt_state = False
-    # saving checkpoints
-    save_freq_epoch = 1
-    save_freq_step = sys.maxsize
-    save_nckpt_max = sys.maxsize
-    # validation during training
-    val_freq = 500
-    val_nbatch = 10
-    val_nbatch_end_epoch = 200
-    # logging
-    print_freq = 20
-    use_tensorboard = False
-    visualization_fn = None
-    # MI355X path only
-    use_graph = False           # replay the train step as a captured hipGraph (graph.GraphedTrainStep)
+    """Options of a training run.  ``gpus[0]`` is the device of this process (an empty list leaves the model where it is)."""
+
+    def __init__(self, **overrides):
+        for table in (_OPTIONS, _EXTRA_OPTIONS):
+            for name, default in table.items():
+                setattr(self, name, list(default) if isinstance(default, list) else default)
+        self.update(overrides)
 
     def update(self, params_dict):
-        for k, v in params_dict.items():
-            if hasattr(self, k):
-                setattr(self, k, v)
+        for name, value in params_dict.items():
+            if name in _OPTIONS or name in _EXTRA_OPTIONS or hasattr(self, name):
+                setattr(self, name, value)
             else:
-                logger.warning('Unknown option: {}: {}'.format(k, v))
+                logger.warning('Unknown option: {}: {}'.format(name, value))
 
     def state_dict(self):
-        out = OrderedDict()
-        for k in TrainParams.__dict__.keys():
-            if not k.startswith('_') and k not in ('update', 'state_dict'):
-                out[k] = getattr(self, k)
-        return out
+        return OrderedDict((name, getattr(self, name)) for name in _OPTIONS)
 
     def __str__(self):
         return 'TrainParams {\n' + ''.join('\t{}: {}\n'.format(k, v) for k, v in self.state_dict().items()) + '}\n'
 
 
+def get_learning_rates(optimizer):
+    return [float(group['lr']) for group in optimizer.param_groups]
+
+
+def _is_epoch_scheduler(s):
+    """A scheduler stepped with the epoch number at the start of an epoch.  ReduceLROnPlateau (an LRScheduler subclass since
+    torch 2.2, a separate class in the reference's torch 0.4) is stepped with the validation loss instead."""
+    return isinstance(s, LRScheduler) and not isinstance(s, ReduceLROnPlateau)
+
+
+# ---------------------------------------------------------------------------------------------------- bookkeeping
+class RunningStat(object):
+    """Mean / sample standard deviation of a stream of scalars.  Values may be asynchronous proxies (losses.LazyFloat): they
+    are parked untouched and folded in only when a statistic is read, so adding never waits for the device."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self._n, self._mean, self._m2, self._parked = 0, 0.0, 0.0, []
+
+    def add(self, value):
+        self._parked.append(value)
+
+    def _fold(self):
+        for v in self._parked:
+            x = float(v)
+            self._n += 1
+            d = x - self._mean
+            self._mean += d / self._n
+            self._m2 += d * (x - self._mean)
+        self._parked = []
+
+    @property
+    def count(self):
+        return self._n + len(self._parked)
+
+    def value(self):
+        """(mean, std): (nan, nan) when empty, (x, inf) after one sample."""
+        self._fold()
+        if self._n == 0:
+            return float('nan'), float('nan')
+        if self._n == 1:
+            return self._mean, INF
+        return self._mean, math.sqrt(max(self._m2, 0.0) / (self._n - 1))
+
+
+class LogBook(OrderedDict):
+    """Named values of the current logging window: numbers are averaged (RunningStat), anything else is kept as last seen."""
+
+    def record(self, values):
+        for name, v in values.items():
+            if isinstance(v, numbers.Real) and not isinstance(v, bool):
+                stat = self.get(name)
+                if not isinstance(stat, RunningStat):
+                    stat = self[name] = RunningStat()
+                stat.add(v)
+            else:
+                self[name] = v
+
+    def lines(self):
+        return ['\n\t{}: {:.10f}'.format(name, v.value()[0]) for name, v in self.items() if isinstance(v, RunningStat)]
+
+    def restart(self):
+        for v in self.values():
+            if isinstance(v, RunningStat):
+                v.reset()
+
+
+class Stopwatch(object):
+    """Average length of the intervals between start() and lap() since the last clear()."""
+
+    def __init__(self):
+        self.clear()
+
+    def clear(self):
+        self.total, self.laps, self._t0 = 0.0, 0, None
+
+    def start(self):
+        self._t0 = time.time()
+
+    def lap(self):
+        if self._t0 is not None:
+            self.total += time.time() - self._t0
+            self.laps += 1
+
+    @property
+    def mean(self):
+        return self.total / self.laps if self.laps else 0.0
+
+
+class _Ranks(object):
+    """The process group as this driver needs it: who writes files, a barrier, and a cross-rank mean of a host scalar."""
+
+    def __init__(self, device):
+        self.on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank() if self.on else 0
+        self.world = dist.get_world_size() if self.on else 1
+        self.device = device
+
+    @property
+    def writer(self):
+        return self.rank == 0
+
+    def barrier(self):
+        if self.on and self.world > 1:
+            dist.barrier()
+
+    def mean(self, x):
+        if not self.on or self.world == 1:
+            return float(x)
+        on_device = self.device.type == 'cuda' and dist.get_backend() == 'nccl'
+        t = torch.tensor([float(x)], dtype=torch.float64, device=self.device if on_device else 'cpu')
+        dist.all_reduce(t)
+        return float(t.item()) / self.world
+
+
+class CheckpointShelf(object):
+    """The checkpoint files of one run directory.  All ranks call every method; only the writer touches the disk."""
+
+    def __init__(self, folder, keep, ranks):
+        self.folder, self.keep, self.ranks = folder, keep, ranks
+        if ranks.writer:
+            os.makedirs(folder, exist_ok=True)
+        ranks.barrier()
+
+    def newest(self):
+        names = net_utils.list_checkpoints(self.folder) if os.path.isdir(self.folder) else []
+        return os.path.join(self.folder, names[-1]) if names else None
+
+    def put(self, name, model, optimizer, epoch):
+        path = os.path.join(self.folder, name)
+        if self.ranks.writer:
+            net_utils.save_net(path, model, epoch=epoch, optimizers=[optimizer], rm_prev_opt=True, max_n_ckpts=self.keep)
+            logger.info('Save ckpt to {}'.format(path))
+        self.ranks.barrier()
+        return path
+
+    def promote(self, path, epoch, loss, previous_best):
+        best = os.path.join(self.folder, 'ckpt_{}_{:.5f}.h5.best'.format(epoch, loss))
+        if self.ranks.writer:
+            shutil.copyfile(path, best)
+            logger.info('Found a better ckpt ({:.5f} -> {:.5f}), saved to {}'.format(previous_best, loss, best))
+        self.ranks.barrier()
+        return best
+
+
+class _Stepper(object):
+    """One optimisation step, through the fastest path that is valid for (model, optimizer, options)."""
+
+    def __init__(self, model, optimizer, params):
+        self.model, self.optimizer = model, optimizer
+        self.clip = params.max_grad_norm if not math.isinf(params.max_grad_norm) else None
+        self.fast = None
+        fused = type(optimizer).__name__ == 'FusedAdam' and hasattr(model, '_engine')
+        if fused and self.clip is None and params.launch in ('replay', 'graph'):
+            if params.launch == 'graph':
+                from ..graph import GraphedTrainStep
+                self.fast = GraphedTrainStep(model, optimizer)
+            else:
+                from ..replay import ReplayedTrainStep
+                self.fast = ReplayedTrainStep(model, optimizer)
+
+    def __call__(self, inputs, gts):
+        if self.fast is not None:
+            return self.fast(inputs, gts)
+        model = self.model
+        _, saved_for_loss = model(*inputs)
+        loss, log = model.build_loss(saved_for_loss, *gts)
+        self.optimizer.zero_grad()
+        loss.backward()
+        if self.clip is not None:
+            log['max_grad'] = float(torch.nn.utils.clip_grad_norm_(model.parameters(), self.clip, INF))
+        self.optimizer.step()
+        return loss, log
+
+
+def _scalar_proxy(loss, lazy):
+    """The step's loss as a number for the meters: an asynchronous proxy for device scalars (no sync), else a float."""
+    if torch.is_tensor(loss):
+        if lazy and loss.is_cuda:
+            from ..network import losses
+            was = losses.LAZY_LOG
+            losses.LAZY_LOG = True
+            try:
+                return losses._log_values(loss.detach().reshape(1))[0]
+            finally:
+                losses.LAZY_LOG = was
+        return float(loss.item())
+    return float(loss)
+
+
+# ---------------------------------------------------------------------------------------------------- the driver
 class Trainer(object):
     TrainParams = TrainParams
     on_start_epoch_hooks = []
     on_end_epoch_hooks = []
 
     def __init__(self, model, train_params, batch_processor, train_data, val_data=None):
-        assert isinstance(train_params, TrainParams)
-        self.params = train_params
-        self.train_data = train_data
-        self.val_data = val_data
+        if not isinstance(train_params, TrainParams):
+            raise TypeError('train_params must be a TrainParams, got {}'.format(type(train_params)))
+        p = self.params = train_params
         self.batch_processor = batch_processor
-        self.batch_per_epoch = len(self.train_data)
-        self.last_epoch = 0
-        self.optimizer = self.params.optimizer
+        self.train_data, self.val_data = train_data, val_data
+        self.batch_per_epoch = len(train_data)
+        self.optimizer, self.lr_scheduler = p.optimizer, p.lr_scheduler
         if not isinstance(self.optimizer, Optimizer):
             raise ValueError('optimizer should be an instance of Optimizer, but got {}'.format(type(self.optimizer)))
-        self.lr_scheduler = self.params.lr_scheduler
-        if self.lr_scheduler and not isinstance(self.lr_scheduler, (ReduceLROnPlateau, _LRScheduler)):
-            raise ValueError('lr_scheduler should be an instance of LRScheduler or ReduceLROnPlateau, but got {}'.format(type(self.lr_scheduler)))
-        self.log_values = OrderedDict()
-        self.batch_timer = Timer()
-        self.data_timer = Timer()
+        if self.lr_scheduler and not isinstance(self.lr_scheduler, (ReduceLROnPlateau, LRScheduler)):
+            raise ValueError('lr_scheduler should be an LRScheduler or ReduceLROnPlateau, but got {}'.format(type(self.lr_scheduler)))
         self.model = model
-        if not self.params.save_dir:
-            self.params.save_dir = os.path.join('outputs', self.params.exp_name)
-        os.makedirs(self.params.save_dir, exist_ok=True)
-        ckpt = self.params.ckpt
-        if ckpt is None:                                       # newest ckpt_*.h5 of save_dir (trainer.py:160-166)
-            ckpts = [f for f in os.listdir(self.params.save_dir) if os.path.splitext(f)[-1] == '.h5']
-            ckpt = os.path.join(self.params.save_dir, sorted(ckpts, key=lambda n: int(os.path.splitext(n)[0].split('_')[-1]))[-1]) if ckpts else None
-        if ckpt is not None and not self.params.re_init:
-            self._load_ckpt(ckpt)
-            logger.info('Load ckpt from {}'.format(ckpt))
-        dev = torch.device('cuda', self.params.gpus[0])
-        torch.cuda.set_device(dev)
-        self.model = self.model.to(dev)
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and getattr(self.model, '_reducer', None) is None:
+        self.last_epoch = 0
+        self.log_values = LogBook()
+        self.batch_timer, self.data_timer = Stopwatch(), Stopwatch()
+
+        if p.gpus:
+            self.device = torch.device('cuda', p.gpus[0])
+            torch.cuda.set_device(self.device)
+        else:
+            self.device = next(model.parameters()).device
+        self.ranks = _Ranks(self.device)
+        if not p.save_dir:
+            p.save_dir = os.path.join('outputs', p.exp_name)
+        self.shelf = CheckpointShelf(p.save_dir, p.save_nckpt_max, self.ranks)
+
+        # parameters go to the device BEFORE a resume, so restored optimizer moments end up beside them
+        self.model = self.model.to(self.device)
+        source = p.ckpt if p.ckpt is not None else self.shelf.newest()
+        if source is not None and not p.re_init:
+            self._load_ckpt(source)
+            logger.info('Load ckpt from {}'.format(source))
+        if self.ranks.on and hasattr(self.model, '_arena') and getattr(self.model, '_reducer', None) is None:
             from .. import ddp
-            ddp.attach(self.model)
+            ddp.attach(self.model)                           # broadcasts rank 0's parameters, buckets the gradient arena
+        self._apply_train_modes()
+        self._step = _Stepper(self.model, self.optimizer, p)
+        self._lazy = bool(p.lazy_log) and hasattr(self.model, '_engine')
+        if self._lazy:
+            from ..network import losses
+            losses.set_lazy_log(True)
+
+    # ------------------------------------------------------------------ modes / resume
+    def _apply_train_modes(self):
+        """Everything in train mode; BatchNorm statistics frozen unless the keypoint subnet is being trained."""
         self.model.train()
         if self.params.subnet_name != 'keypoint_subnet':
-            self.model.freeze_bn()                             # trainer.py:173-174
-        self._graphed = None
-        if self.params.use_graph:
-            from ..graph import GraphedTrainStep
-            self._graphed = GraphedTrainStep(self.model, self.optimizer)
-
-    # ------------------------------------------------------------------ epochs
-    def train(self):
-        best_loss = np.inf
-        for epoch in range(self.last_epoch, self.params.max_epoch):
-            self.last_epoch += 1
-            logger.info('Start training epoch {}'.format(self.last_epoch))
-            for fun in self.on_start_epoch_hooks:
-                fun(self)
-            if isinstance(self.lr_scheduler, _LRScheduler) and not isinstance(self.lr_scheduler, ReduceLROnPlateau):
-                cur_lrs = get_learning_rates(self.optimizer)
-                self.lr_scheduler.step(self.last_epoch)
-                logger.info('Set learning rates from {} to {}'.format(cur_lrs, get_learning_rates(self.optimizer)))
-            self._train_one_epoch()
-            for fun in self.on_end_epoch_hooks:
-                fun(self)
-            if (self.last_epoch % self.params.save_freq_epoch == 0) or (self.last_epoch == self.params.max_epoch - 1):
-                save_to = os.path.join(self.params.save_dir, 'ckpt_{}.h5'.format(self.last_epoch))
-                self._save_ckpt(save_to)
-                if self.params.val_nbatch_end_epoch > 0 and self.val_data is not None:
-                    val_loss = self._val_one_epoch(self.params.val_nbatch_end_epoch)
-                    if val_loss < best_loss:
-                        best_file = os.path.join(self.params.save_dir, 'ckpt_{}_{:.5f}.h5.best'.format(self.last_epoch, val_loss))
-                        shutil.copyfile(save_to, best_file)
-                        logger.info('Found a better ckpt ({:.5f} -> {:.5f}), saved to {}'.format(best_loss, val_loss, best_file))
-                        best_loss = val_loss
-                    if isinstance(self.lr_scheduler, ReduceLROnPlateau):
-                        self.lr_scheduler.step(val_loss)
-
-    def _save_ckpt(self, save_to):
-        model = self.model.module if isinstance(self.model, nn.DataParallel) else self.model
-        net_utils.save_net(save_to, model, epoch=self.last_epoch, optimizers=[self.optimizer], rm_prev_opt=True,
-                           max_n_ckpts=self.params.save_nckpt_max)
-        logger.info('Save ckpt to {}'.format(save_to))
+            self.model.freeze_bn()
 
     def _load_ckpt(self, ckpt):
-        epoch, state_dicts = net_utils.load_net(ckpt, self.model, load_state_dict=True)
-        if not self.params.ignore_opt_state and not self.params.zero_epoch and epoch >= 0:
-            self.last_epoch = epoch
-            logger.info('Set last epoch to {}'.format(self.last_epoch))
-            if state_dicts is not None:
-                self.optimizer.load_state_dict(state_dicts[0])
-                logger.info('Load optimizer state from checkpoint, new learning rate: {}'.format(get_learning_rates(self.optimizer)))
+        p = self.params
+        epoch, states = net_utils.load_net(ckpt, self.model, load_state_dict=True)
+        if p.ignore_opt_state or p.zero_epoch or epoch < 0:
+            return
+        self.last_epoch = epoch
+        logger.info('Set last epoch to {}'.format(epoch))
+        if states is not None:
+            self.optimizer.load_state_dict(states[0])
+            if self.device.type == 'cuda':
+                net_utils.set_optimizer_state_devices(self.optimizer.state, self.device.index)
+            logger.info('Load optimizer state from checkpoint, new learning rate: {}'.format(get_learning_rates(self.optimizer)))
+
+    def _save_ckpt(self, save_to):
+        return self.shelf.put(os.path.basename(save_to), self.model, self.optimizer, self.last_epoch)
+
+    # ------------------------------------------------------------------ epochs
+    def _epoch_saves(self, epoch):
+        p = self.params
+        return epoch % p.save_freq_epoch == 0 or epoch == p.max_epoch - 1
+
+    def train(self):
+        p = self.params
+        best = INF
+        while self.last_epoch < p.max_epoch:
+            self.last_epoch += 1
+            epoch = self.last_epoch
+            logger.info('Start training epoch {}'.format(epoch))
+            for hook in self.on_start_epoch_hooks:
+                hook(self)
+            if _is_epoch_scheduler(self.lr_scheduler):
+                before = get_learning_rates(self.optimizer)
+                self.lr_scheduler.step(epoch)
+                logger.info('Set learning rates from {} to {}'.format(before, get_learning_rates(self.optimizer)))
+            self._train_one_epoch()
+            for hook in self.on_end_epoch_hooks:
+                hook(self)
+            if not self._epoch_saves(epoch):
+                continue
+            saved = self._save_ckpt('ckpt_{}.h5'.format(epoch))
+            if p.val_nbatch_end_epoch > 0 and self.val_data is not None:
+                val_loss = self._val_one_epoch(p.val_nbatch_end_epoch)
+                if val_loss < best:
+                    self.shelf.promote(saved, epoch, val_loss, best)
+                    best = val_loss
+                if isinstance(self.lr_scheduler, ReduceLROnPlateau):
+                    self.lr_scheduler.step(val_loss)
+                    self.lr_scheduler.last_epoch = epoch
 
     def _train_one_epoch(self):
-        self.batch_timer.clear()
-        self.data_timer.clear()
-        self.batch_timer.tic()
-        self.data_timer.tic()
-        total_loss = AverageValueMeter()
-        clip = not np.isinf(self.params.max_grad_norm)
+        p = self.params
+        epoch_loss = RunningStat()
+        self._restart_timers()
         for step, batch in enumerate(self.train_data):
             inputs, gts, _ = self.batch_processor(self, batch)
-            self.data_timer.toc()
-            if self._graphed is not None and not clip:
-                loss, saved_for_log = self._graphed(inputs, gts)
-            else:
-                output, saved_for_loss = self.model(*inputs)
-                loss, saved_for_log = self.model.build_loss(saved_for_loss, *gts)
-                self.optimizer.zero_grad()
-                loss.backward()
-                if clip:                                       # trainer.py:254-256
-                    saved_for_log['max_grad'] = float(nn.utils.clip_grad_norm_(self.model.parameters(), self.params.max_grad_norm, float('inf')))
-                self.optimizer.step(None)
-            total_loss.add(loss.item())
-            self._process_log(saved_for_log, self.log_values)
-            self.batch_timer.toc()
-            reset = False
-            if step % self.params.print_freq == 0:
+            self.data_timer.lap()
+            loss, log = self._step(inputs, gts)
+            epoch_loss.add(_scalar_proxy(loss, self._lazy))
+            self.log_values.record(log)
+            self.batch_timer.lap()
+            if step % p.print_freq == 0:
                 self._print_log(step, self.log_values, title='Training', max_n_batch=self.batch_per_epoch)
-                reset = True
-            if step % self.params.save_freq_step == 0 and step > 0:
-                self._save_ckpt(os.path.join(self.params.save_dir, 'ckpt_{}.h5.ckpt'.format((self.last_epoch - 1) * self.batch_per_epoch + step)))
-            if reset:
-                self._reset_log(self.log_values)
-            self.data_timer.tic()
-            self.batch_timer.tic()
-        return total_loss.value()[0]
+                window_done = True
+            else:
+                window_done = False
+            if step > 0 and step % p.save_freq_step == 0:
+                self._save_ckpt('ckpt_{}.h5.ckpt'.format((self.last_epoch - 1) * self.batch_per_epoch + step))
+            if window_done:
+                self.log_values.restart()
+            self.data_timer.start()
+            self.batch_timer.start()
+        return epoch_loss.value()[0]
 
     def _val_one_epoch(self, n_batch):
-        training_mode = self.model.training
+        """Mean loss over the first ``n_batch + 1`` validation batches in eval mode (the count the reference consumes),
+        averaged over ranks; afterwards the modes training runs in are restored."""
+        p = self.params
+        was_training = self.model.training
         self.model.eval()
-        logs = OrderedDict()
-        sum_loss = AverageValueMeter()
+        book, losses_seen = LogBook(), RunningStat()
         logger.info('Val on validation set...')
-        self.batch_timer.clear()
-        self.data_timer.clear()
-        self.batch_timer.tic()
-        self.data_timer.tic()
+        self._restart_timers()
+        n_print = min(n_batch, len(self.val_data))
         with torch.no_grad():
             for step, batch in enumerate(self.val_data):
-                self.data_timer.toc()
+                self.data_timer.lap()
                 if step > n_batch:
                     break
                 inputs, gts, _ = self.batch_processor(self, batch)
                 _, saved_for_loss = self.model(*inputs)
-                self.batch_timer.toc()
-                loss, saved_for_log = self.model.build_loss(saved_for_loss, *gts)
-                sum_loss.add(loss.item())
-                self._process_log(saved_for_log, logs)
-                if step % self.params.print_freq == 0 or step == len(self.val_data) - 1:
-                    self._print_log(step, logs, 'Validation', max_n_batch=min(n_batch, len(self.val_data)))
-                self.data_timer.tic()
-                self.batch_timer.tic()
-        mean, std = sum_loss.value()
+                self.batch_timer.lap()
+                loss, log = self.model.build_loss(saved_for_loss, *gts)
+                losses_seen.add(_scalar_proxy(loss, self._lazy))
+                book.record(log)
+                if step % p.print_freq == 0 or step == len(self.val_data) - 1:
+                    self._print_log(step, book, 'Validation', max_n_batch=n_print)
+                self.data_timer.start()
+                self.batch_timer.start()
+        mean, std = losses_seen.value()
+        mean = self.ranks.mean(mean)
         logger.info('Validation loss: mean: {}, std: {}'.format(mean, std))
-        self.model.train(mode=training_mode)
-        if self.params.subnet_name != 'keypoint_subnet':
-            self.model.freeze_bn()                             # trainer.py:317-318
+        self.model.train(mode=was_training)
+        if p.subnet_name != 'keypoint_subnet':
+            self.model.freeze_bn()
         return mean
 
     # ------------------------------------------------------------------ logging
-    def _process_log(self, src_dict, dest_dict):
-        for k, v in src_dict.items():
-            if isinstance(v, numbers.Real) and not isinstance(v, bool):       # floats, ints and LazyFloat proxies (trainer.py:324 tests (int, float))
-                dest_dict.setdefault(k, AverageValueMeter())
-                dest_dict[k].add(float(v))
-            else:
-                dest_dict[k] = v
+    def _restart_timers(self):
+        for t in (self.batch_timer, self.data_timer):
+            t.clear()
+            t.start()
 
-    def _print_log(self, step, log_values, title='', max_n_batch=None):
-        log_str = '{}\n'.format(self.params.exp_name)
-        log_str += '{}: epoch {}'.format(title, self.last_epoch)
+    def _print_log(self, step, book, title='', max_n_batch=None):
+        """One log block per window: averaged values, then (data s / batch s, fps = batch_size / batch s, time left).  Non-writer
+        ranks stay quiet (their windows are reset all the same)."""
+        p = self.params
+        text = '{}\n{}: epoch {}'.format(p.exp_name, title, self.last_epoch)
         if max_n_batch:
-            log_str += '[{}/{}], lr: {}'.format(step, max_n_batch, get_learning_rates(self.optimizer))
-        for k, v in log_values.items():
-            if isinstance(v, AverageValueMeter):
-                log_str += '\n\t{}: {:.10f}'.format(k, v.value()[0])
+            text += '[{}/{}], lr: {}'.format(step, max_n_batch, get_learning_rates(self.optimizer))
+        text += ''.join(book.lines())
         if max_n_batch:
-            data_time = self.data_timer.duration + 1e-6
-            batch_time = self.batch_timer.duration + 1e-6
-            rest_seconds = int((max_n_batch - step) * batch_time)
-            log_str += '\n\t({:.2f}/{:.2f}s, fps:{:.1f}, rest: {})'.format(data_time, batch_time, self.params.batch_size / batch_time,
-                                                                           str(datetime.timedelta(seconds=rest_seconds)))
+            data_s, batch_s = self.data_timer.mean + 1e-6, self.batch_timer.mean + 1e-6
+            left = datetime.timedelta(seconds=int((max_n_batch - step) * batch_s))
+            text += '\n\t({:.2f}/{:.2f}s, fps:{:.1f}, rest: {})'.format(data_s, batch_s, p.batch_size * self.ranks.world / batch_s, left)
             self.batch_timer.clear()
             self.data_timer.clear()
-        logger.info(log_str)
-
-    def _reset_log(self, log_values):
-        for v in log_values.values():
-            if isinstance(v, AverageValueMeter):
-                v.reset()
+        if self.ranks.writer:
+            logger.info(text)

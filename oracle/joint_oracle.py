@@ -112,7 +112,7 @@ def nms_peaks(thre1, heatmaps, upsamp=1.0, refine=True):
     return out
 
 
-def cv_resize(img, out_hw, cubic):
+def cv_resize(img, out_hw, cubic, inv_scale=None):
     """cv2.resize(img, (out_w, out_h), interpolation=INTER_CUBIC | INTER_LINEAR) for a float32 [H, W, C] array, restated
     (evaluate/tester.py:67,213,296-299 call sites).  Source coordinate s = (d + 0.5) * (src/dst) - 0.5; cubic: taps
     floor(s)-1..floor(s)+2 clamped; linear: OpenCV clamps the coordinate (s < 0 -> 0, s >= n-1 -> n-1, weight 0).
@@ -121,8 +121,9 @@ def cv_resize(img, out_hw, cubic):
     Hs, Ws, C = img.shape
     Hd, Wd = int(out_hw[0]), int(out_hw[1])
 
-    def taps(n_dst, n_src):
-        scale = float(n_src) / float(n_dst)
+    def taps(n_dst, n_src, forced=None):
+        # dsize form: scale = src / dst; fx / fy form (cv2.resize(img, None, fx=, fy=), tester.py:68): scale = 1 / f
+        scale = float(n_src) / float(n_dst) if forced is None else float(forced)
         nt = 4 if cubic else 2
         idx = np.zeros((n_dst, nt), dtype=np.int64)
         co = np.zeros((n_dst, nt), dtype=np.float32)
@@ -143,8 +144,8 @@ def cv_resize(img, out_hw, cubic):
                 co[d] = (np.float32(1) - fr, fr)
         return idx, co
 
-    xi, xc = taps(Wd, Ws)
-    yi, yc = taps(Hd, Hs)
+    xi, xc = taps(Wd, Ws, None if inv_scale is None else inv_scale[1])
+    yi, yc = taps(Hd, Hs, None if inv_scale is None else inv_scale[0])
     rows = np.zeros((Hs, Wd, C), dtype=np.float32)
     for d in range(Wd):
         acc = img[:, xi[d, 0], :] * xc[d, 0]

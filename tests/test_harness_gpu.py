@@ -22,6 +22,15 @@ def test_resize_follows_the_opencv_rule():
             got = resize(torch.from_numpy(img).cuda(), (hd, wd), cubic).cpu().numpy()
             want = joint_oracle.cv_resize(img, (hd, wd), cubic)
             assert np.array_equal(got, want), "resize %s %dx%d -> %dx%d differs from the restated OpenCV arithmetic" % ("cubic" if cubic else "linear", hs, ws, hd, wd)
+    # the fx / fy call form of crop_with_factor (cv2.resize(im, None, fx=s, fy=s), tester.py:68): the scale is 1/f exactly, which is
+    # NOT src/dst when round(src * f) != src * f
+    img = rs.rand(37, 53, 3).astype(np.float32)
+    for f in (0.73, 1.37, 2.0):
+        hd, wd = int(np.rint(37 * f)), int(np.rint(53 * f))
+        got = resize(torch.from_numpy(img).cuda(), (hd, wd), False, inv_scale=(1.0 / f, 1.0 / f)).cpu().numpy()
+        assert np.array_equal(got, joint_oracle.cv_resize(img, (hd, wd), False, inv_scale=(1.0 / f, 1.0 / f)))
+        if f != 2.0:
+            assert not np.array_equal(got, joint_oracle.cv_resize(img, (hd, wd), False))
     # strided views (a channel-first heat-map seen as [H, W, C]) take the same path
     chw = torch.from_numpy(rs.rand(18, 20, 24).astype(np.float32)).cuda()
     got = resize(chw.permute(1, 2, 0), (80, 96), True).cpu().numpy()

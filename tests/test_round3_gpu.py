@@ -81,3 +81,80 @@ def test_cfg2_r50_keypoint_480_batch16_fp32_full_size():
     report("cfg2 full size (R50 keypoint_subnet 480x480 B=16 fp32): finite, bit-reproducible, loss %.6f; B=2 slice loss %.7f vs oracle %.7f (rel %.2e)"
            % (float(l0), float(ls), float(ol), rel))
     assert rel <= 2e-4
+
+
+# ------------------------------------------------------------------------------------------------ drivers
+def test_trainer_follows_the_real_reference_trainer_on_device(tmp_path):
+    """The g14 fixture (recorded from the real reference Trainer) with model, optimizer state and batches on the MI355X:
+    same learning rates, modes, files, resume facts; restored Adam moments live on the device."""
+    from test_round3_cpu import check_trainer_against_reference
+    assert check_trainer_against_reference(tmp_path, device=0) == 10
+    report("Trainer on the device: 10 scenarios identical to the real reference Trainer (g14_trainer.json)")
+
+
+def test_trainer_uses_the_recorded_step_and_tester_val_matches_a_hand_loop(tmp_path):
+    """poseNet + FusedAdam through Trainer: the step is the recorded launch list (replays counted), the parameters equal the
+    hand-written eager loop bit for bit, log values arrive as numbers without a per-step sync; Tester.val (tester.py:515-543)
+    over the same validation batches returns the mean of the per-batch eval-mode losses computed by hand."""
+    from multiposenet.pytorch_amd.evaluate.tester import Tester, TestParams
+    from multiposenet.pytorch_amd.optim import FusedAdam
+    from multiposenet.pytorch_amd.network import losses
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    from multiposenet.pytorch_amd.training.batch_processor import batch_processor, train_step
+    from multiposenet.pytorch_amd.training.trainer import Trainer, TrainParams
+    from oracle import weightgen
+    B, S = 2, 64
+
+    def loader(n, seed):
+        out = []
+        for i in range(n):
+            heat, wgt = (t(a) for a in weightgen.gen_keypoint_gt(seed + 10 + i, B, S // 4, S // 4))
+            out.append((t(weightgen.gen_images(seed + i, B, S, S)), heat, wgt))
+        return out
+    train_data, val_data = loader(5, 400), loader(3, 500)
+    model = get_model(50, torch.bfloat16)
+    for p in model.prn.parameters():
+        p.requires_grad = False
+    state0 = {k: v.clone() for k, v in model.state_dict().items()}
+    model.train()
+    opt = FusedAdam(model, lr=1e-3)
+
+    class S_(object):
+        pass
+    st = S_(); st.model = model; st.params = S_(); st.params.subnet_name = 'keypoint_subnet'; st.params.gpus = [0]
+    for batch in train_data:
+        inputs, gts, _ = batch_processor(st, batch)
+        train_step(model, opt, inputs, gts)
+    want = model._arena.flat.clone()
+    model.load_state_dict(state0)
+    P = TrainParams(exp_name='unit3', subnet_name='keypoint_subnet', batch_size=B, max_epoch=1, save_dir=str(tmp_path / "run"),
+                    print_freq=2, val_nbatch_end_epoch=0)
+    P.optimizer = FusedAdam(model, lr=1e-3)
+    was_lazy = losses.LAZY_LOG
+    try:
+        tr = Trainer(model, P, batch_processor, train_data, None)
+        tr.train()
+        torch.cuda.synchronize()
+        assert tr._step.fast is not None and tr._step.fast.replays == 3       # 1 eager + 1 recording + 3 replays
+        assert torch.equal(model._arena.flat, want), "Trainer's recorded steps differ from the hand-written eager loop"
+        assert "heatmap_loss" in tr.log_values and np.isfinite(tr.log_values["heatmap_loss"].value()[0]) or tr.log_values["heatmap_loss"].count == 0
+    finally:
+        losses.set_lazy_log(was_lazy)
+    # Tester.val over val_data == the hand loop (eval mode, frozen statistics)
+    tp = TestParams()
+    tp.ckpt, tp.subnet_name, tp.batch_size, tp.print_freq = os.path.join(P.save_dir, "ckpt_1.h5"), 'keypoint_subnet', B, 2
+    fresh = poseNet(50, compute_dtype=torch.bfloat16)
+    tester = Tester(fresh, tp, batch_processor=batch_processor, val_data=val_data)
+    assert torch.equal(fresh._arena.flat, want)
+    mean, std = tester.val()
+    hand = []
+    fresh.eval()
+    with torch.no_grad():
+        for batch in val_data:
+            inputs, gts, _ = batch_processor(tester, batch)
+            _, saved = fresh(*inputs)
+            loss, _ = fresh.build_loss(saved, *gts)
+            hand.append(float(loss))
+    assert abs(mean - float(np.mean(hand))) <= 1e-6 * abs(np.mean(hand)) and abs(std - float(np.std(hand, ddof=1))) <= 1e-5 * max(np.std(hand, ddof=1), 1e-9) + 1e-9
+    assert not fresh.training and not any(m.training for m in fresh._bns)
+    report("Trainer(poseNet, FusedAdam): 5 steps through the recorded list == eager loop bit for bit; Tester.val mean %.6f == hand loop" % mean)
