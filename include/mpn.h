@@ -107,9 +107,26 @@ int mpn_conv_stats_tiles(const MpnConvParams* p);
 /* output-channel rows of the tile (256 / 128 / 64 / 32) the launcher will pick: names the kernel instantiation */
 int mpn_conv_tile_rows(const MpnConvParams* p);
 /* 1 when the launcher will take conv_igemm_s3_kernel (3x3, stride 1, pad 1, 16-bit operands, dense input: the pixel tile of a kernel
- * row lands once and serves its three taps), 0 for conv_igemm_kernel: names the kernel instantiation */
+ * row lands once and serves its three taps), 2 when it will take conv_pw_kernel (below), 0 for conv_igemm_kernel: names the kernel
+ * instantiation */
 int mpn_conv_shared_tile(const MpnConvParams* p);
 int mpn_conv_forward(const MpnConvParams* p, void* stream);
+
+/* Pointwise kernel with the pixel tile resident in LDS (csrc/conv_pw.hip): the 1x1 / stride-1 "expand" convolutions of a
+ * Bottleneck (network/fpn.py:14,18,28-33 — conv3 forward, conv1 input gradient) whose contraction is short (Cin = 64 / 128 / 256)
+ * and whose output is wide (Cout >= 256, multiple of 64): one workgroup per 128-pixel tile computes ALL output channels from a
+ * pixel tile that lands in LDS once.  16-bit element types, dense tensors, epilogue = scale / bias / ReLU / same-size residual /
+ * ReLU after it / accumulate / forward or backward BatchNorm tile statistics (no in-launch finalize).  Results are bit-identical to
+ * mpn_conv_forward's generic kernel (same k order, same rounding points); the statistics differ in summation order only.
+ * mpn_conv_pw_supported: 1 when the kernel serves p.  mpn_conv_pw_selected: 1 when mpn_conv_forward will route p to it by itself
+ * (supported, its epilogue class enabled by MPN_PW_EPI_MASK — default: none, the kernel measured no step-level gain, DESIGN.md —
+ * and at least mpn_conv_pw_set_min_tiles() pixel tiles, default 96; a threshold of 0 routes everything supported;
+ * mpn_conv_shared_tile() then returns 2).  mpn_conv_pw_set_min_tiles(t): t >= 0 sets the threshold, returns the
+ * previous value.  mpn_conv_pw_forward: launches it for any supported p (MPN_E_UNSUPPORTED otherwise). */
+int mpn_conv_pw_supported(const MpnConvParams* p);
+int mpn_conv_pw_selected(const MpnConvParams* p);
+int mpn_conv_pw_set_min_tiles(int tiles);
+int mpn_conv_pw_forward(const MpnConvParams* p, void* stream);
 
 typedef struct MpnWgradParams {
     const void* x;        /* forward input activations (gathered)                                 */

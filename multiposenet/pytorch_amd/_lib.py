@@ -72,6 +72,10 @@ SIGNATURES = {
     "mpn_prn_build_maps": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, ctypes.c_double, _vp, _vp, _vp, _vp, _vp]),
     "mpn_prn_scores": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mpn_conv_stats_tiles": (_i, [_PC]),
+    "mpn_conv_pw_supported": (_i, [_PC]),
+    "mpn_conv_pw_selected": (_i, [_PC]),
+    "mpn_conv_pw_set_min_tiles": (_i, [_i]),
+    "mpn_conv_pw_forward": (_i, [_PC, _vp]),
     "mpn_conv_tile_rows": (_i, [_PC]),
     "mpn_conv_shared_tile": (_i, [_PC]),
     "mpn_conv_forward": (_i, [_PC, _vp]),
@@ -146,7 +150,7 @@ SIGNATURES = {
 }
 
 # entry points that return a count, not a status
-_COUNT_FUNCS = {"mpn_conv_stats_tiles", "mpn_conv_tile_rows", "mpn_conv_shared_tile", "mpn_conv_wgrad_chunks", "mpn_conv_wgrad_seg_plan", "mpn_conv_wgrad_kernel_id", "mpn_bn_bwd_chunks", "mpn_channel_sum_chunks",
+_COUNT_FUNCS = {"mpn_conv_stats_tiles", "mpn_conv_tile_rows", "mpn_conv_shared_tile", "mpn_conv_pw_supported", "mpn_conv_pw_selected", "mpn_conv_pw_set_min_tiles", "mpn_conv_wgrad_chunks", "mpn_conv_wgrad_seg_plan", "mpn_conv_wgrad_kernel_id", "mpn_bn_bwd_chunks", "mpn_channel_sum_chunks",
                 "mpn_mse_chunks", "mpn_focal_blocks", "mpn_bce_chunks", "mpn_nms_workspace_bytes", "mpn_nms_batched_workspace_bytes", "mpn_version"}
 
 _lib = None

@@ -927,6 +927,7 @@ extern "C" int mpn_conv_tile_rows(const MpnConvParams* p) {
 
 extern "C" int mpn_conv_shared_tile(const MpnConvParams* p) {
     if (!p) return MPN_E_BADARG;
+    if (mpn_conv_pw_selected(p)) return 2;
     const long P = (long)p->B * p->Ho * p->Wo;
     return conv_uses_s3(*p, pick_tc(*p, p->nseg > 0 ? (long)p->seg_tile0[p->nseg] : (P + kTP - 1) / kTP)) ? 1 : 0;
 }
@@ -969,6 +970,7 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
         if (xb + row >= 0xfffffff0LL || (int64_t)(p.Cout + 1) * row >= 0xfffffff0LL) return MPN_E_UNSUPPORTED;
     }          // activation is applied before the residual stage
     hipStream_t st = (hipStream_t)stream;
+    if (mpn_conv_pw_selected(&p)) return mpn_conv_pw_forward(&p, stream);   // short-K wide-output 1x1: pixel tile resident in LDS (conv_pw.hip)
     if (p.dtype == MPN_F32) return launch_conv<float, false>(p, st);       // OT == T == float
     if (p.dtype == MPN_F16) return p.out_f32 ? launch_conv<f16_t, true>(p, st) : launch_conv<f16_t, false>(p, st);
     return p.out_f32 ? launch_conv<bf16_t, true>(p, st) : launch_conv<bf16_t, false>(p, st);

@@ -243,7 +243,9 @@ class Tester(object):
         flipped_heat, _ = self._get_outputs(multiplier, img.flip(1).contiguous())
         heatmaps = self._handle_heat(orig_heat, flipped_heat)
         param = {'thre1': 0.1, 'thre2': 0.05, 'thre3': 0.5}
-        joint_list = get_joint_list(img, param, heatmaps[:, :, :18].contiguous(), 1)
+        # the averaged maps are float64 as in the reference (np.zeros accumulator); the peak kernel takes float32, so they are
+        # rounded ONCE here (the reference's find_peaks / cv2 refinement run on the float64 maps: a <= 1 ulp(f32) deviation)
+        joint_list = get_joint_list(img, param, heatmaps[:, :, :18].float().contiguous(), 1)
         results = self.prn_process(self._body_joints(joint_list), orig_bbox_all[1], file_name, image_id)
         for result in results:                                    # tester.py:167-175: COCO keypoint order
             kp = result['keypoints']

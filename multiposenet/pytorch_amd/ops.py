@@ -355,7 +355,7 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         tiles = call("mpn_conv_stats_tiles", ctypes.byref(p))
         stats = torch.empty((tiles, Cout, 2), dtype=torch.float32, device=dev)
         p.stats = stats.data_ptr()
-        if bn_fin is not None and tiles <= FIN_MAX_TILES:
+        if bn_fin is not None and tiles <= FIN_MAX_TILES and not call("mpn_conv_pw_selected", ctypes.byref(p)):
             # the last workgroup of every channel tile turns the tile partials into the BatchNorm coefficients (no finalize launch):
             # the BNState comes back in the stats slot
             gamma, beta, rm, rv, momentum, eps = bn_fin
@@ -378,7 +378,7 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         p.bnb_mean, p.bnb_invstd = st.mean.data_ptr(), st.invstd.data_ptr()
         p.bnb_scale, p.bnb_shift = st.scale.data_ptr(), st.shift.data_ptr()
         p.bnb_relu = 1 if relu else 0
-        if len(bnb) > 4 and bnb[4] is not None and tiles <= FIN_MAX_TILES:
+        if len(bnb) > 4 and bnb[4] is not None and tiles <= FIN_MAX_TILES and not call("mpn_conv_pw_selected", ctypes.byref(p)):
             # ... and the last workgroup of every channel tile finishes the reduction: dgamma / dbeta and the (k1, k2, k3) of
             # dy = k1*g + k2*y + k3 (mpn_bn_bwd_finalize's work); the coefficient tensor comes back in the stats slot
             gamma, train, dgamma, dbeta = bnb[4]
@@ -400,8 +400,12 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         flops = 2.0 * x.B * Ho * Wo * Cout * live * min(Cin, x.C if x_geom is None else Cin)
         # the name rocprofv3 prints for this instantiation (tools/rocprof_summary.py spelling)
         general = (scale is not None or bias is not None or res is not None or accumulate or act != 0 or Cout % tc != 0 or bnb is not None)
-        name = ("conv_igemm_s3_kernel" if call("mpn_conv_shared_tile", ctypes.byref(p)) == 1 else "conv_igemm_kernel") + "<%s, %d, 128, %s, %s>" % (dtype_name(dt), tc,
+        kind = call("mpn_conv_shared_tile", ctypes.byref(p))
+        name = ("conv_igemm_s3_kernel" if kind == 1 else "conv_igemm_kernel") + "<%s, %d, 128, %s, %s>" % (dtype_name(dt), tc,
                                                           "true" if p.out_f32 else "false", "true" if general else "false")
+        if kind == 2:          # pixel tile resident in LDS (csrc/conv_pw.hip)
+            name = "conv_pw_kernel<%s, %d, %d>" % (dtype_name(dt), 8 if Cout >= 512 else 4,
+                                                    2 if (accumulate or bnb is not None) else (1 if (scale is not None or bias is not None or act != 0 or res is not None) else 0))
         if KERNEL_EVENTS.detail:
             es = 2 if is16(dt) else 4
             byts = x.B * H * W * Cin * es + x.B * Ho * Wo * p.Cout_store * (4 if out_f32 else es) * (2 if accumulate else 1) \

@@ -158,3 +158,82 @@ def test_trainer_uses_the_recorded_step_and_tester_val_matches_a_hand_loop(tmp_p
     assert abs(mean - float(np.mean(hand))) <= 1e-6 * abs(np.mean(hand)) and abs(std - float(np.std(hand, ddof=1))) <= 1e-5 * max(np.std(hand, ddof=1), 1e-9) + 1e-9
     assert not fresh.training and not any(m.training for m in fresh._bns)
     report("Trainer(poseNet, FusedAdam): 5 steps through the recorded list == eager loop bit for bit; Tester.val mean %.6f == hand loop" % mean)
+
+
+# ------------------------------------------------------------------------------------------------ pixel-tile-resident 1x1 kernel
+def _pw_threshold(v):
+    from multiposenet.pytorch_amd._lib import call
+    return call("mpn_conv_pw_set_min_tiles", int(v))
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_pw_kernel_is_bit_identical_to_the_generic_kernel(dt):
+    """csrc/conv_pw.hip against conv_igemm.hip on the same operands (through mpn_conv_forward with the routing threshold at 0 and
+    at infinity): outputs bit-identical for every epilogue (plain, forward BN statistics, folded-BN scale/shift + ReLU + residual
+    + ReLU, bias + ReLU, accumulate, accumulate + BN-backward statistics with and without the ReLU mask), tile statistics equal
+    up to summation order; plus the plain result against a float64 CPU convolution.  Sizes include a ragged last pixel tile."""
+    from helpers import check_close, from_act, rnd, rng_normal, to_act, w_krsc
+    from multiposenet.pytorch_amd import ops
+    from multiposenet.pytorch_amd._lib import ConvParams, call
+    old = _pw_threshold(-1)
+    try:
+        for (B, H, W, Cin, Cout) in ((2, 17, 19, 256, 1024), (1, 16, 16, 64, 256), (3, 9, 11, 128, 512), (1, 13, 10, 256, 256), (2, 8, 8, 64, 512)):
+            x = rnd(dt, rng_normal(1, B, Cin, H, W))
+            w = rnd(dt, rng_normal(2, Cout, Cin, 1, 1) * 0.05)
+            xa, wk = to_act(x, dt), w_krsc(w, dt)
+            res = to_act(rnd(dt, rng_normal(3, B, Cout, H, W)), dt)
+            scale = (torch.rand(Cout, generator=torch.Generator().manual_seed(4)) + 0.5).cuda()
+            bias = rng_normal(5, Cout).cuda()
+            prev = rnd(dt, rng_normal(6, B, Cout, H, W))
+            by, bz = to_act(rnd(dt, rng_normal(7, B, Cout, H, W)), dt), to_act(rnd(dt, rng_normal(8, B, Cout, H, W)), dt)
+            st = ops.BNState(Cout, torch.device("cuda"))
+            st.mean.copy_(rng_normal(9, Cout) * 0.1); st.invstd.copy_(torch.rand(Cout) + 0.5); st.scale.fill_(1.0); st.shift.fill_(0.0)
+            cases = {
+                "plain": dict(),
+                "stats": dict(want_stats=True),
+                "fold+relu+res+relu": dict(scale=scale, bias=bias, act=3, res=res, res_mode=1),
+                "bias+relu": dict(bias=bias, act=1),
+                "res": dict(res=res, res_mode=1),
+                "acc": dict(accumulate=True),
+                "acc+bnb(relu,z)": dict(accumulate=True, bnb=(by, bz, st, True)),
+                "bnb(no relu)": dict(bnb=(by, None, st, False)),
+            }
+            for name, kw in cases.items():
+                outs = []
+                for thr in (1 << 30, 0):
+                    _pw_threshold(thr)
+                    kw2 = dict(kw)
+                    if kw.get("accumulate") or "bnb" in kw:
+                        kw2["out"] = to_act(prev, dt)
+                    y, s = ops.conv_forward(xa, wk, Cout, 1, 1, 1, 0, **kw2)
+                    torch.cuda.synchronize()
+                    outs.append((y.t.clone(), None if s is None else s.clone()))
+                p = ConvParams()
+                (yg, sg), (yp, sp) = outs
+                tag = "%s pw %s B%d %dx%d %d->%d" % (str(dt).split(".")[-1], name, B, H, W, Cin, Cout)
+                assert torch.equal(yg.view(torch.int16), yp.view(torch.int16)), tag + ": output differs from the generic kernel"
+                if sg is not None:
+                    err = float((sg.double() - sp.double()).abs().max()) / max(float(sg.double().abs().max()), 1e-9)
+                    assert sg.shape == sp.shape and err <= 2e-5, tag + ": tile statistics differ (%.2e)" % err
+                if name == "plain":
+                    ref = torch.nn.functional.conv2d(x.double(), w.double()).float()
+                    check_close(tag + " vs f64", from_act(ops.Act(yp, Cout)), rnd(dt, ref), dt)
+        # the routing itself: selected for the bench shape, not for what the kernel does not serve
+        _pw_threshold(old)
+        p = ConvParams()
+        p.B, p.H, p.W, p.Ho, p.Wo, p.Cin, p.Cout, p.Cout_store = 32, 30, 30, 30, 30, 256, 1024, 1024
+        p.R = p.S = p.stride = 1
+        p.dtype = ops.dtype_code(dt)
+        p.x_sW, p.x_sH, p.x_sB, p.y_sP, p.y_sB = 256, 30 * 256, 900 * 256, 1024, 900 * 1024
+        import ctypes
+        ref_p = ctypes.byref(p)
+        assert call("mpn_conv_pw_supported", ref_p) == 1
+        assert call("mpn_conv_pw_selected", ref_p) == (1 if os.environ.get("MPN_PW_EPI_MASK", "0") not in ("", "0") else 0)     # routed only on request
+        _pw_threshold(0)
+        assert call("mpn_conv_pw_selected", ref_p) == 1 and call("mpn_conv_shared_tile", ref_p) == 2
+        p.Cin = 512
+        assert call("mpn_conv_pw_supported", ref_p) == 0
+        _pw_threshold(old)
+    finally:
+        _pw_threshold(old)
+    report("conv_pw_kernel (%s): 8 epilogues x 5 shapes bit-identical to conv_igemm_kernel, statistics within 2e-5" % str(dt).split(".")[-1])
