@@ -75,6 +75,9 @@ typedef struct MpnConvParams {
      * when the forward had no residual input).  Statistics use the values as stored (after rounding to the element type).    */
     const void* bnb_y;
     const void* bnb_z;
+    const uint8_t* bnb_mask; /* alternative to bnb_z: the ReLU mask as bits written by mpn_bn_act_forward(mask=...) — one byte per
+                              * 16-byte chunk of z (8 channels of a 16-bit type, 4 of f32), bit k = (z[chunk*V + k] > 0), dense
+                              * [pixels][Cout_store / V]; 1/16 of z's bytes.  Takes precedence over bnb_z.                       */
     const float* bnb_mean;
     const float* bnb_invstd;
     const float* bnb_scale;
@@ -204,9 +207,11 @@ int mpn_bn_finalize_train(const float* stats, int tiles, int C, int64_t count, c
 int mpn_bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, float* mean, float* invstd,
                          float* scale, float* shift, void* stream);
-/* z = act(y*scale + shift [+ res]);  all [P][Cs] dense pixel-major with pixel stride Cs */
+/* z = act(y*scale + shift [+ res]);  all [P][Cs] dense pixel-major with pixel stride Cs.  mask (optional, with relu): the sign
+ * bits of the STORED z, one byte per 16-byte chunk ([P][Cs / V], V = 8 for 16-bit types, 4 for f32; bit k = z[chunk*V + k] > 0) —
+ * what the backward of relu(bn(.) + shortcut) (network/fpn.py:30-33) needs of z, at 1/16 of its bytes. */
 int mpn_bn_act_forward(const void* y, const void* res, void* z, const float* scale, const float* shift,
-                       int64_t P, int C, int Cs, int relu, int dtype, void* stream);
+                       int64_t P, int C, int Cs, int relu, int dtype, uint8_t* mask, void* stream);
 /* backward, stage 1: g = dz * (z > 0 if relu); partial sums of g and g*xhat per channel.
  * With relu and z == NULL the mask is recomputed as (y*mask_scale + mask_shift) > 0 — the forward's own expression
  * (valid when the forward had no residual input), which saves reading z. */
@@ -216,9 +221,11 @@ int mpn_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float*
  * dy = k1*g + k2*y + k3  (train: full batch-stat backward; train=0: k1 = gamma*invstd, k2 = k3 = 0) */
 int mpn_bn_bwd_finalize(const float* partial, int chunks, int C, int64_t count, const float* gamma, const float* mean,
                         const float* invstd, int train, float* dgamma, float* dbeta, float* coef, void* stream);
-/* backward, stage 3: dy = k1*g + k2*y + k3 (k2/k3 may be NULL = 0); dres (optional) receives / accumulates g */
+/* backward, stage 3: dy = k1*g + k2*y + k3 (k2/k3 may be NULL = 0); dres (optional) receives / accumulates g.  With relu the mask
+ * comes from `mask` bits (mpn_bn_act_forward) when given, else from z, else it is recomputed from y (mask_scale / mask_shift). */
 int mpn_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* k1, const float* k2, const float* k3,
-                     const float* mask_scale, const float* mask_shift, void* dy, void* dres, int dres_accumulate, int64_t P, int C, int Cs, int relu, int dtype, void* stream);
+                     const float* mask_scale, const float* mask_shift, void* dy, void* dres, int dres_accumulate, int64_t P, int C, int Cs, int relu, int dtype,
+                     const uint8_t* mask, void* stream);
 int mpn_bn_bwd_chunks(int64_t P, int Cs, int dtype);
 
 /* ---------------------------------------------------------------------------------------------

@@ -37,7 +37,7 @@ class ConvParams(ctypes.Structure):
         ("dtype", ctypes.c_int32), ("out_f32", ctypes.c_int32),
         ("nseg", ctypes.c_int32), ("seg_H", ctypes.c_int32 * 5), ("seg_W", ctypes.c_int32 * 5), ("seg_tile0", ctypes.c_int32 * 6),
         ("seg_x", ctypes.c_void_p * 5), ("seg_y", ctypes.c_void_p * 5),
-        ("bnb_y", ctypes.c_void_p), ("bnb_z", ctypes.c_void_p), ("bnb_mean", ctypes.c_void_p), ("bnb_invstd", ctypes.c_void_p),
+        ("bnb_y", ctypes.c_void_p), ("bnb_z", ctypes.c_void_p), ("bnb_mask", ctypes.c_void_p), ("bnb_mean", ctypes.c_void_p), ("bnb_invstd", ctypes.c_void_p),
         ("bnb_scale", ctypes.c_void_p), ("bnb_shift", ctypes.c_void_p), ("bnb_partial", ctypes.c_void_p), ("bnb_relu", ctypes.c_int32),
         ("fin_counters", ctypes.c_void_p), ("fin_gamma", ctypes.c_void_p), ("fin_beta", ctypes.c_void_p), ("fin_rm", ctypes.c_void_p),
         ("fin_rv", ctypes.c_void_p), ("fin_out", ctypes.c_void_p), ("fin_dgamma", ctypes.c_void_p), ("fin_dbeta", ctypes.c_void_p),
@@ -95,10 +95,10 @@ SIGNATURES = {
     "mpn_stem_pack_image": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp]),
     "mpn_bn_finalize_train": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "mpn_bn_finalize_eval": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
-    "mpn_bn_act_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "mpn_bn_act_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "mpn_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
     "mpn_bn_bwd_finalize": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
-    "mpn_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
+    "mpn_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _vp, _vp]),
     "mpn_bn_bwd_chunks": (_i, [_i64, _i, _i]),
     "mpn_maxpool3x3s2_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mpn_maxpool3x3s2_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -123,7 +123,7 @@ __global__ void bn_finalize_eval_kernel(int C, const float* __restrict__ gamma, 
 template <typename T>
 __global__ void __launch_bounds__(256) bn_act_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ z,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
-                                                     long P, int C, int Cs, int relu, int iters) {
+                                                     long P, int C, int Cs, int relu, int iters, unsigned char* __restrict__ mask) {
     constexpr int V = Vec16<T>::N;
     const Geo<T> q(Cs);
     float sc[V], sf[V];
@@ -145,6 +145,12 @@ __global__ void __launch_bounds__(256) bn_act_kernel(const T* __restrict__ y, co
             a.v[k] = (q.c0 + k < C) ? x : 0.f;
         }
         a.store(z + off);
+        if (mask) {                                   // sign bits of the value as stored (rounded to the element type)
+            unsigned bits = 0;
+#pragma unroll
+            for (int k = 0; k < V; ++k) bits |= (Elem<T>::round(a.v[k]) > 0.f ? 1u : 0u) << k;
+            mask[p * q.G + q.g] = (unsigned char)bits;
+        }
     }
 }
 
@@ -238,14 +244,16 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ k1p, const float* __restrict__ k2p,
                                                            const float* __restrict__ k3p, const float* __restrict__ mscale,
                                                            const float* __restrict__ mshift, T* __restrict__ dy, T* __restrict__ dres,
-                                                           int dres_acc, long P, int C, int Cs, int relu, int iters) {
+                                                           int dres_acc, long P, int C, int Cs, int relu, int iters,
+                                                           const unsigned char* __restrict__ mask) {
     constexpr int V = Vec16<T>::N;
     const Geo<T> q(Cs);
     float k1[V], k2[V], k3[V];
     load_coef<V>(k1p, q.c0, C, k1, 0.f);
     load_coef<V>(k2p, q.c0, C, k2, 0.f);
     load_coef<V>(k3p, q.c0, C, k3, 0.f);
-    const bool remask = relu && z == nullptr;
+    const bool bits = relu && mask != nullptr;      // ReLU mask from the forward's sign bits (1 byte per 16-byte chunk)
+    const bool remask = relu && !bits && z == nullptr;
     float sc[V], sf[V];
     if (remask) { load_coef<V>(mscale, q.c0, C, sc, 0.f); load_coef<V>(mshift, q.c0, C, sf, 0.f); }
     const bool need_y = ((dy != nullptr) && (k2p != nullptr)) || remask;
@@ -257,12 +265,15 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
         Vec16<T> d, o, x, out, r;
         d.load(dz + off);
         if (need_y) x.load(y + off);
-        if (relu && !remask) o.load(z + off);
+        if (relu && !remask && !bits) o.load(z + off);
+        unsigned mb = 0;
+        if (bits) mb = mask[p * q.G + q.g];
         if (dres && dres_acc) r.load(dres + off);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             float gk = d.v[k];
             if (remask) o.v[k] = x.v[k] * sc[k] + sf[k];
+            if (bits) o.v[k] = ((mb >> k) & 1u) ? 1.f : 0.f;
             if (relu && !(o.v[k] > 0.f)) gk = 0.f;
             const bool live = q.c0 + k < C;
             out.v[k] = live ? (k1[k] * gk + (k2p ? k2[k] * x.v[k] : 0.f) + k3[k]) : 0.f;
@@ -314,14 +325,14 @@ extern "C" int mpn_bn_finalize_eval(int C, const float* gamma, const float* beta
 }
 
 extern "C" int mpn_bn_act_forward(const void* y, const void* res, void* z, const float* scale, const float* shift,
-                                  int64_t P, int C, int Cs, int relu, int dtype, void* stream) {
-    MPN_CHECK_ARG(y && z && scale && shift && P > 0 && C > 0 && Cs >= C);
+                                  int64_t P, int C, int Cs, int relu, int dtype, uint8_t* mask, void* stream) {
+    MPN_CHECK_ARG(y && z && scale && shift && P > 0 && C > 0 && Cs >= C && (!mask || relu));
     const int V = dtype == MPN_F32 ? 4 : 8;
     MPN_CHECK_ARG(geo_ok(Cs, V) && C % 4 == 0);
     const int lanes = geo_lanes(Cs, V), iters = pick_iters(P, lanes);
     dim3 grid((unsigned)((P + (long)lanes * iters - 1) / ((long)lanes * iters)), (unsigned)geo_yblocks(Cs, V));
     MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)y, (const T*)res,
-                           (T*)z, scale, shift, (long)P, C, Cs, relu, iters));
+                           (T*)z, scale, shift, (long)P, C, Cs, relu, iters, (unsigned char*)mask));
     return mpn_launch_status();
 }
 
@@ -357,16 +368,17 @@ extern "C" int mpn_bn_bwd_finalize(const float* partial, int chunks, int C, int6
 
 extern "C" int mpn_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* k1, const float* k2, const float* k3,
                                 const float* mask_scale, const float* mask_shift, void* dy, void* dres, int dres_accumulate, int64_t P, int C, int Cs, int relu, int dtype,
-                                void* stream) {
+                                const uint8_t* mask, void* stream) {
     MPN_CHECK_ARG(dz && (dy || dres) && P > 0 && C > 0 && Cs >= C);
     MPN_CHECK_ARG(!dy || k1);
     MPN_CHECK_ARG(!(dy && k2) || y);
-    MPN_CHECK_ARG(!relu || z || (mask_scale && mask_shift && y));
+    MPN_CHECK_ARG(!relu || z || mask || (mask_scale && mask_shift && y));
     const int V = dtype == MPN_F32 ? 4 : 8;
     MPN_CHECK_ARG(geo_ok(Cs, V) && C % 4 == 0);
     const int lanes = geo_lanes(Cs, V), iters = pick_iters(P, lanes);
     dim3 grid((unsigned)((P + (long)lanes * iters - 1) / ((long)lanes * iters)), (unsigned)geo_yblocks(Cs, V));
     MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dz, (const T*)z,
-                           (const T*)y, k1, k2, k3, mask_scale, mask_shift, (T*)dy, (T*)dres, dres_accumulate, (long)P, C, Cs, relu, iters));
+                           (const T*)y, k1, k2, k3, mask_scale, mask_shift, (T*)dy, (T*)dres, dres_accumulate, (long)P, C, Cs, relu, iters,
+                           (const unsigned char*)mask));
     return mpn_launch_status();
 }

@@ -344,7 +344,9 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
     // its EV channels, reduced over the tile after the store loop
     const bool bnb = GENERAL && pk.bnb_partial != nullptr;
     const OT* __restrict__ Ybn = (const OT*)pk.bnb_y;
-    const OT* __restrict__ Zbn = (const OT*)pk.bnb_z;
+    const unsigned char* __restrict__ Mbn = pk.bnb_mask;         // sign bits of z (one byte per 16-byte chunk) instead of z itself
+    const OT* __restrict__ Zbn = Mbn ? nullptr : (const OT*)pk.bnb_z;
+    const int mrow = p.Cout_store / EV;                           // mask bytes per pixel
     float bs1[EV], bs2[EV], bmu[EV], bis[EV], bsc[EV], bsf[EV];
     if (bnb) {
 #pragma unroll
@@ -386,6 +388,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
             bool live[G];
             long yo[G];
             u32x4_t l_res[G], l_acc[G], l_y[G], l_z[G];
+            unsigned l_m[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 live[g] = pix < P && ccol < p.Cout_store && !(dbg & 128);
@@ -406,6 +409,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                     if (bnb) {
                         l_y[g] = *reinterpret_cast<const u32x4_t*>(Ybn + yo[g]);
                         if (Zbn) l_z[g] = *reinterpret_cast<const u32x4_t*>(Zbn + yo[g]);
+                        if (Mbn) l_m[g] = Mbn[(long)pix * mrow + ccol / EV];
                     }
                 }
                 pix += PPI; rem += PPI;
@@ -444,7 +448,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                     for (int e = 0; e < EV; ++e) {
                         float gg = dzv.v[e];
                         if (pk.bnb_relu) {
-                            const float zv = Zbn ? zz.v[e] : yy.v[e] * bsc[e] + bsf[e];
+                            const float zv = Mbn ? (((l_m[g] >> e) & 1u) ? 1.f : 0.f) : (Zbn ? zz.v[e] : yy.v[e] * bsc[e] + bsf[e]);
                             if (!(zv > 0.f)) gg = 0.f;
                         }
                         bs1[e] += gg;
@@ -961,7 +965,8 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     MPN_CHECK_ARG(!p.fin_counters || (((p.stats != nullptr) != (p.bnb_partial != nullptr)) && p.fin_count > 0 && !p.nseg &&
                                       (p.stats ? p.fin_out != nullptr : true)));
     MPN_CHECK_ARG(!p.bnb_partial || (p.bnb_y && p.bnb_mean && p.bnb_invstd && !p.out_f32 && !p.nseg && !p.stats && !p.act &&
-                                     (!p.bnb_relu || p.bnb_z || (p.bnb_scale && p.bnb_shift))));
+                                     (!p.bnb_relu || p.bnb_z || p.bnb_mask || (p.bnb_scale && p.bnb_shift)) &&
+                                     (!p.bnb_mask || (p.y_sB == (int64_t)p.Ho * p.Wo * p.y_sP && p.y_sP == p.Cout_store))));
     {   // buffer descriptors address at most 4 GB per operand
         const int64_t ts = p.dtype == MPN_F32 ? 4 : 2;
         const int64_t row = (int64_t)p.R * p.S * p.Cin * ts;

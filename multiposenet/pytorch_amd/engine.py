@@ -92,6 +92,9 @@ class Engine(object):
         self.fold_bn = os.environ.get("MPN_FOLD_BN", "1") != "0"
         # the BatchNorm finalize steps (tile partials -> coefficients) run inside the producing conv launch (last-arriving workgroup)
         self.fuse_bn_finalize = os.environ.get("MPN_BN_FUSED_FINALIZE", "1") != "0"
+        # relu(bn3(.) + shortcut): the forward also writes the sign bits of z (1/16 of its bytes); both backward passes that need
+        # the ReLU mask (statistics in the dgrad epilogue, bn_bwd_apply) read those instead of z
+        self.bn_mask_bits = os.environ.get("MPN_BN_MASK_BITS", "1") != "0"
 
     def side_stream(self, device):
         """Second HIP stream for weight/bias gradients.  They are off the backward critical path (only the
@@ -427,7 +430,7 @@ class Engine(object):
             ctx.bn_train_ran = True
         else:
             st = ops.bn_finalize_eval(layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var, layer.eps)
-        z = ops.bn_act(y, st, relu, res=res, tag=tag)
+        z = ops.bn_act(y, st, relu, res=res, tag=tag, want_mask=bool(self.bn_mask_bits and ctx.train and relu and res is not None))
         if ctx.train:
             z.needs_grad = bool(y.needs_grad or layer.weight.requires_grad or layer.bias.requires_grad
                                 or (res is not None and res.needs_grad))

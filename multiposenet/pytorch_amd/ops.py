@@ -85,7 +85,7 @@ class Act(object):
 
     Cs (channel storage) is a multiple of 32; lanes [C, Cs) hold zeros (see include/mpn.h).
     """
-    __slots__ = ("t", "B", "H", "W", "C", "Cs", "needs_grad", "tag", "seg", "cons", "bn_src")
+    __slots__ = ("t", "B", "H", "W", "C", "Cs", "needs_grad", "tag", "seg", "cons", "bn_src", "mask")
 
     def __init__(self, t, C, needs_grad=False, tag=""):
         self.t = t
@@ -96,6 +96,7 @@ class Act(object):
         self.seg = None          # (flat buffer, index) when this activation is one level of a pyramid group (alloc_seg)
         self.cons = 0            # gradient contributions still to come in backward (engine: last-contributor detection)
         self.bn_src = None       # (y, BNState, relu, has_residual) when this is the output of a BatchNorm
+        self.mask = None         # sign bits of this tensor (uint8 [P, Cs / V]) when bn_act produced them for the backward pass
 
     @staticmethod
     def empty(B, H, W, C, dtype, device, needs_grad=False, tag=""):
@@ -375,6 +376,8 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         p.bnb_partial = stats.data_ptr()
         p.bnb_y = by.t.data_ptr()
         p.bnb_z = bz.t.data_ptr() if bz is not None else None
+        if bz is not None and bz.mask is not None:          # the ReLU mask as bits (bn_act(want_mask=True)): z itself is not read
+            p.bnb_mask, p.bnb_z = bz.mask.data_ptr(), None
         p.bnb_mean, p.bnb_invstd = st.mean.data_ptr(), st.invstd.data_ptr()
         p.bnb_scale, p.bnb_shift = st.scale.data_ptr(), st.shift.data_ptr()
         p.bnb_relu = 1 if relu else 0
@@ -540,10 +543,14 @@ def bn_finalize_eval(gamma, beta, rm, rv, eps=1e-5):
     return st
 
 
-def bn_act(y, st, relu, res=None, needs_grad=False, tag=""):
+def bn_act(y, st, relu, res=None, needs_grad=False, tag="", want_mask=False):
+    """z = act(y * scale + shift [+ res]).  want_mask (with relu): also the sign bits of z, one byte per 16-byte chunk — all the
+    backward of relu(bn(.) + shortcut) needs of z (the ReLU mask), at 1/16 of z's bytes (z.mask)."""
     z = Act(torch.empty_like(y.t), y.C, needs_grad, tag)
+    if want_mask and relu:
+        z.mask = torch.empty((y.P, y.Cs // (4 if y.t.dtype == torch.float32 else 8)), dtype=torch.uint8, device=y.t.device)
     call("mpn_bn_act_forward", ptr(y.t), ptr(res.t) if res is not None else None, ptr(z.t), ptr(st.scale), ptr(st.shift),
-         y.P, y.C, y.Cs, 1 if relu else 0, dtype_code(y.t.dtype), stream_ptr())
+         y.P, y.C, y.Cs, 1 if relu else 0, dtype_code(y.t.dtype), ptr(z.mask), stream_ptr())
     return z
 
 
@@ -580,10 +587,11 @@ def bn_backward(dz, z, y, st, gamma, relu, train, dgamma=None, dbeta=None, want_
     if want_dy or dres is not None:
         if want_dy:
             dy = Act(torch.empty_like(y.t), C)
-        call("mpn_bn_bwd_apply", ptr(dz.t), ptr(z.t) if (relu and not remask) else None, ptr(y.t), ptr(k1), ptr(k2), ptr(k3),
+        bits = z.mask if (relu and not remask) else None
+        call("mpn_bn_bwd_apply", ptr(dz.t), ptr(z.t) if (relu and not remask and bits is None) else None, ptr(y.t), ptr(k1), ptr(k2), ptr(k3),
              ptr(st.scale) if remask else None, ptr(st.shift) if remask else None,
              ptr(dy.t) if dy is not None else None, ptr(dres.t) if dres is not None else None,
-             1 if dres_acc else 0, P, C, Cs, 1 if relu else 0, dc, stream_ptr())
+             1 if dres_acc else 0, P, C, Cs, 1 if relu else 0, dc, ptr(bits), stream_ptr())
     return dy
 
 

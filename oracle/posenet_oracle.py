@@ -24,6 +24,60 @@ import torch.nn.functional as F
 
 BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
 
+# ----------------------------------------------------------------------------------------------
+# Optional storage-precision model.  The HIP path in bf16 / f16 keeps every activation and every activation gradient in the 16-bit
+# type and accumulates in fp32: operands are rounded when they are STORED (conv outputs after bias / ReLU, BatchNorm outputs after
+# the residual add and ReLU, FPN top-down sums, input-gradient tensors), never inside a contraction.  `rounding(dtype)` makes this
+# restatement round at those same points — forward value and, straight through, the gradient arriving at that tensor — so a bf16
+# run can be judged against fp32 arithmetic that carries the SAME rounding noise instead of against noise-free fp32 (where
+# batch-statistics BatchNorm amplifies the difference by ~6 % per bottleneck and hides real errors).  Outputs the HIP path produces
+# in f32 straight from its accumulators (convfin, convfin_k2..5, the tower outputs) are not rounded.
+# ----------------------------------------------------------------------------------------------
+_QUANT = None
+
+
+class _RoundST(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dt):
+        ctx.dt = dt
+        return x.to(dt).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dt).float(), None
+
+
+class _RoundGrad(torch.autograd.Function):
+    """f32 head outputs: the value stays f32, the gradient coming back from the loss is stored in the 16-bit type (import_grad)."""
+
+    @staticmethod
+    def forward(ctx, x, dt):
+        ctx.dt = dt
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dt).float(), None
+
+
+def _q(x):
+    return x if _QUANT is None else _RoundST.apply(x, _QUANT)
+
+
+class rounding(object):
+    """with rounding(torch.bfloat16): ... — see above."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _QUANT
+        self.prev, _QUANT = _QUANT, self.dtype
+
+    def __exit__(self, *exc):
+        global _QUANT
+        _QUANT = self.prev
+
 
 # ----------------------------------------------------------------------------------------------
 # backbone + dual FPN                                            network/fpn.py
@@ -35,30 +89,36 @@ def _bn(sd, prefix, x, training, momentum=0.1):
                         training=training, momentum=momentum, eps=1e-5)
 
 
-def _conv(sd, name, x, stride=1, padding=0):
-    return F.conv2d(x, sd[name + ".weight"], sd.get(name + ".bias"), stride=stride, padding=padding)
+def _conv(sd, name, x, stride=1, padding=0, f32_out=False):
+    w = sd[name + ".weight"]
+    if _QUANT is not None:
+        w = w + (w.detach().to(_QUANT).float() - w.detach())      # operand copy in the 16-bit type, gradient straight to the f32 master
+    y = F.conv2d(x, w, sd.get(name + ".bias"), stride=stride, padding=padding)
+    if f32_out:
+        return y if _QUANT is None else _RoundGrad.apply(y, _QUANT)
+    return _q(y)
 
 
 def bottleneck(sd, p, x, stride, has_down, bn_training):
     """fpn.py:28-34 (Bottleneck.forward); stride sits on the 3x3 (fpn.py:16)."""
-    out = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x), bn_training))
-    out = F.relu(_bn(sd, p + ".bn2", _conv(sd, p + ".conv2", out, stride=stride, padding=1), bn_training))
+    out = _q(F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x), bn_training)))
+    out = _q(F.relu(_bn(sd, p + ".bn2", _conv(sd, p + ".conv2", out, stride=stride, padding=1), bn_training)))
     out = _bn(sd, p + ".bn3", _conv(sd, p + ".conv3", out), bn_training)
     if has_down:      # fpn.py:22-26
-        sc = _bn(sd, p + ".downsample.1", _conv(sd, p + ".downsample.0", x, stride=stride), bn_training)
+        sc = _q(_bn(sd, p + ".downsample.1", _conv(sd, p + ".downsample.0", x, stride=stride), bn_training))
     else:             # fpn.py:21 (empty Sequential == identity)
         sc = x
-    return F.relu(out + sc)
+    return _q(F.relu(out + sc))
 
 
 def upsample_add(x, y):
     """fpn.py:84-95: nearest upsample of x to y's exact (H, W), then add."""
-    return F.interpolate(x, size=y.shape[2:], mode="nearest") + y
+    return _q(F.interpolate(x, size=y.shape[2:], mode="nearest") + y)
 
 
 def fpn_forward(sd, x, layers, bn_training, pre="fpn."):
     """fpn.py:97-126.  Returns ([fp2,fp3,fp4,fp5], [p3,p4,p5,p6,p7], [c2..c5])."""
-    c1 = F.relu(_bn(sd, pre + "bn1", _conv(sd, pre + "conv1", x, stride=2, padding=3), bn_training))
+    c1 = _q(F.relu(_bn(sd, pre + "bn1", _conv(sd, pre + "conv1", _q(x), stride=2, padding=3), bn_training)))
     c1 = F.max_pool2d(c1, kernel_size=3, stride=2, padding=1)
     feats = []
     cur = c1
@@ -103,17 +163,17 @@ def keypoint_head(sd, kp_feats, with_intermediate):
     p2, p3, p4, p5 = kp_feats
     saved = []
     if with_intermediate:   # posenet.py:296-299
-        saved.append(_conv(sd, "convfin_k2", p2))
-        saved.append(_up(_conv(sd, "convfin_k3", p3), 2))
-        saved.append(_up(_conv(sd, "convfin_k4", p4), 4))
-        saved.append(_up(_conv(sd, "convfin_k5", p5), 8))
+        saved.append(_conv(sd, "convfin_k2", p2, f32_out=True))
+        saved.append(_up(_conv(sd, "convfin_k3", p3, f32_out=True), 2))
+        saved.append(_up(_conv(sd, "convfin_k4", p4, f32_out=True), 4))
+        saved.append(_up(_conv(sd, "convfin_k5", p5, f32_out=True), 8))
     # posenet.py:302-309 — no activation between convt and convs
     q5 = _conv(sd, "convs1", _conv(sd, "convt1", p5, padding=1), padding=1)
     q4 = _conv(sd, "convs2", _conv(sd, "convt2", p4, padding=1), padding=1)
     q3 = _conv(sd, "convs3", _conv(sd, "convt3", p3, padding=1), padding=1)
     q2 = _conv(sd, "convs4", _conv(sd, "convt4", p2, padding=1), padding=1)
     cat = torch.cat((_up(q5, 8), _up(q4, 4), _up(q3, 2), q2), 1)            # posenet.py:311-315
-    pred = _conv(sd, "convfin", F.relu(_conv(sd, "conv2", cat, padding=1)))
+    pred = _conv(sd, "convfin", F.relu(_conv(sd, "conv2", cat, padding=1)), f32_out=True)
     saved.append(pred)
     return pred, saved
 
@@ -122,7 +182,7 @@ def _tower(sd, pre, x):
     out = x
     for i in (1, 2, 3, 4):
         out = F.relu(_conv(sd, "%s.conv%d" % (pre, i), out, padding=1))
-    return _conv(sd, pre + ".output", out, padding=1)
+    return _conv(sd, pre + ".output", out, padding=1, f32_out=True)
 
 
 def regression_model(sd, x):

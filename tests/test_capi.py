@@ -121,7 +121,7 @@ def test_entry_points_reject_bad_arguments_without_touching_the_gpu():
     assert L.mpn_weight_transpose(nul, one, 8, 1, 8, 8, 1, nul) == BAD
     assert L.mpn_weight_transpose(one, one, 8, 1, 8, 4, 1, nul) == BAD    # Cout_pad < Cout
     assert L.mpn_weight_transpose_batched(one, one, nul, 3, 10, 1, nul) == BAD
-    assert L.mpn_bn_act_forward(nul, nul, one, one, one, 16, 8, 8, 1, 1, nul) == BAD
+    assert L.mpn_bn_act_forward(nul, nul, one, one, one, 16, 8, 8, 1, 1, nul, nul) == BAD
     assert L.mpn_bn_bwd_reduce(one, nul, one, one, one, nul, nul, one, 1, 16, 32, 32, 1, 1, nul) == BAD   # relu without z or mask coefficients
     assert L.mpn_gt_heatmaps(nul, one, 1, 1, one, 4, 4, 4.0, 7.0, nul) == BAD
     assert L.mpn_gt_heatmaps(one, one, 1, 1, one, 4, 4, 0.0, 7.0, nul) == BAD
