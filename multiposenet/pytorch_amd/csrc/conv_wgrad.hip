@@ -346,6 +346,8 @@ __device__ __forceinline__ const void* rfl_ptr(const void* q) {
 // allocation (the level lookup costs ~30 VGPRs of address arithmetic that the compiler no longer proves uniform)
 template <typename T, int TM, int TN, bool SEG>
 __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, long chunk_pixels) {
+    const bool ablate_stores = (chunk_pixels >> 62) & 1;     // MPN_WGRAD_ABLATE=2 (tools only): how much do the partial stores cost?
+    chunk_pixels &= ~(1L << 62);
     constexpr int KP = 32, NST = 3;
     constexpr int ROWA = TM * 2, ROWB = TN * 2;              // bytes per pixel row of each tile
     constexpr int A_BYTES = KP * ROWA, B_BYTES = KP * ROWB;
@@ -520,7 +522,7 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, lo
                 const float4 o = *reinterpret_cast<const float4*>(q);
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
             }
-            *reinterpret_cast<float4*>(q) = v;
+            if (!ablate_stores || v.x == 123.456f) *reinterpret_cast<float4*>(q) = v;
         }
     }
 }
@@ -652,6 +654,10 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st, bool reduce = true) {
     if (p.nseg > 0) chunk_pixels = p.seg_chunk_pixels;
     const long grid = tilesM * tilesN * p.R * p.S * p.chunks;
     if (grid <= 0 || grid > 0x7fffffffL || P >= 0x7fffffffL) return MPN_E_BADARG;
+    // ablations for tools/ (results are WRONG with either bit): 1 = no reduction launch, 2 = the slices do not store their partials
+    static const int ablate = getenv("MPN_WGRAD_ABLATE") ? atoi(getenv("MPN_WGRAD_ABLATE")) : 0;
+    if ((ablate & 2) && p.chunks > 1) chunk_pixels |= (1L << 62);
+    if ((ablate & 1) && p.chunks > 1) reduce = false;
     int rc;
     const dim3 g((unsigned)grid), blk(256);
     if (sizeof(T) == 2 && wgrad_uses_dma(p)) {
