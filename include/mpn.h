@@ -40,6 +40,10 @@ typedef struct MpnConvParams {
     const float* bias;    /* optional [Cout] f32                                                  */
     const float* scale;   /* optional [Cout] f32 per-channel multiplier applied before bias       */
     const void* res;      /* optional residual (same element type as y)                           */
+    const uint8_t* res_mask; /* optional, res_mode 1 only: the residual is multiplied by these mask bits (layout of bnb_mask /
+                              * mpn_bn_act_forward's mask, dense [pixels][Cout_store / V]) before it is added — the gradient of
+                              * relu(bn3(.) + shortcut) w.r.t. the shortcut is dz * (z > 0): the dgrad launch that completes the
+                              * shortcut's gradient reads dz and the bits instead of a materialised copy (network/fpn.py:30-33)  */
     float* stats;         /* optional [tilesP][Cout][2] per-tile (sum, sumsq) partials (BN train) */
     int64_t x_sB, x_sH, x_sW;
     int64_t y_sB, y_sP;

@@ -24,7 +24,7 @@ class MpnError(RuntimeError):
 class ConvParams(ctypes.Structure):
     _fields_ = [
         ("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("y", ctypes.c_void_p),
-        ("bias", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("res", ctypes.c_void_p),
+        ("bias", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("res", ctypes.c_void_p), ("res_mask", ctypes.c_void_p),
         ("stats", ctypes.c_void_p),
         ("x_sB", ctypes.c_int64), ("x_sH", ctypes.c_int64), ("x_sW", ctypes.c_int64),
         ("y_sB", ctypes.c_int64), ("y_sP", ctypes.c_int64),

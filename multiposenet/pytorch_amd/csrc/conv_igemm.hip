@@ -388,7 +388,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
             bool live[G];
             long yo[G];
             u32x4_t l_res[G], l_acc[G], l_y[G], l_z[G];
-            unsigned l_m[G];
+            unsigned l_m[G], l_rm[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 live[g] = pix < P && ccol < p.Cout_store && !(dbg & 128);
@@ -404,6 +404,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                             ro = (long)b * p.res_sB + (long)(rh * (unsigned)p.res_W + rw) * p.res_sP;
                         }
                         l_res[g] = *reinterpret_cast<const u32x4_t*>(Rz + ro + ccol);
+                        if (pk.res_mask) l_rm[g] = pk.res_mask[(long)pix * mrow + ccol / EV];
                     }
                     if (p.accumulate) l_acc[g] = *reinterpret_cast<const u32x4_t*>(Y + yo[g]);
                     if (bnb) {
@@ -424,6 +425,10 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                     Vec16<OT> a; a.load(reinterpret_cast<const OT*>(&v));
                     if (p.res_mode != 0) {
                         Vec16<OT> r; r.load(reinterpret_cast<const OT*>(&l_res[g]));
+                        if (pk.res_mask) {
+#pragma unroll
+                            for (int e = 0; e < EV; ++e) r.v[e] = ((l_rm[g] >> e) & 1u) ? r.v[e] : 0.f;
+                        }
 #pragma unroll
                         for (int e = 0; e < EV; ++e) a.v[e] += r.v[e];
                     }
@@ -960,6 +965,7 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     MPN_CHECK_ARG(!(p.accumulate && p.act != 0));
     MPN_CHECK_ARG(p.act >= 0 && p.act <= 3 && (p.act != 3 || p.res_mode == 1));
     MPN_CHECK_ARG(p.res_mode == 0 || p.res != nullptr);
+    MPN_CHECK_ARG(!p.res_mask || (p.res_mode == 1 && !p.nseg && p.y_sB == (int64_t)p.Ho * p.Wo * p.y_sP && p.y_sP == p.Cout_store));
     MPN_CHECK_ARG(!(p.stats && (p.bias || p.scale || p.res_mode || p.accumulate || p.act)));
     MPN_CHECK_ARG(!((p.res_mode || p.accumulate) && p.act && p.act != 3));
     MPN_CHECK_ARG(!p.fin_counters || (((p.stats != nullptr) != (p.bnb_partial != nullptr)) && p.fin_count > 0 && !p.nseg &&

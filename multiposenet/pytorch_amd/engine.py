@@ -39,6 +39,8 @@ class Ctx(object):
         self.bnb = {}            # id(BN output Act) -> per-tile backward statistics produced by the launch that completed its gradient
         self.side_deferred = []  # side-stream closures held back for later fork points (Engine.side_defer)
         self.side_count = 0
+        self.lazy_res = {}       # id(Act) -> (dz, mask bits): shortcut gradient dz * (z > 0) NOT materialised; the convolution whose
+                                 # input gradient completes that Act adds it in its epilogue (Engine.defer_shortcut_grad)
 
     def gbuf(self, act, dtype=None):
         """Gradient buffer for ``act``: returns (Act, existed)."""
@@ -95,6 +97,9 @@ class Engine(object):
         # relu(bn3(.) + shortcut): the forward also writes the sign bits of z (1/16 of its bytes); both backward passes that need
         # the ReLU mask (statistics in the dgrad epilogue, bn_bwd_apply) read those instead of z
         self.bn_mask_bits = os.environ.get("MPN_BN_MASK_BITS", "1") != "0"
+        # ... and the shortcut gradient of an identity block, dz * (z > 0), is not written by bn_bwd_apply at all: conv1's input-gradient
+        # launch (the only other contribution to that tensor) reads dz and the bits in its epilogue (MpnConvParams.res_mask)
+        self.defer_shortcut_grad = os.environ.get("MPN_DEFER_SHORTCUT_GRAD", "1") != "0"
 
     def side_stream(self, device):
         """Second HIP stream for weight/bias gradients.  They are off the backward critical path (only the
@@ -275,6 +280,7 @@ class Engine(object):
                 if x.needs_grad:
                     self.w_t(ctx, layer)       # make the transposed operand now (weights may change before backward)
                     x.cons += 1
+                    x.conv_cons += 1
                 if res is not None and res.needs_grad:
                     res.cons += 1
                 ctx.tape.append(lambda: self._conv_bwd(ctx, x, layer, y, act, res, res_mode))
@@ -291,6 +297,12 @@ class Engine(object):
                 self._grad_done(ctx, bias)
             if x.needs_grad:
                 x.cons -= 1
+                x.conv_cons -= 1
+                lazy = ctx.lazy_res.pop(id(x), None)
+                if lazy is not None:            # the deferred shortcut gradient has no convolution to ride on: materialise it
+                    g, existed = ctx.gbuf(x)
+                    assert not existed
+                    ops.masked_copy(lazy[0], lazy[1], g)
             if res is not None and res.needs_grad:
                 res.cons -= 1
             return
@@ -327,7 +339,9 @@ class Engine(object):
                 self._grad_done(ctx, bias)
         if x.needs_grad:
             x.cons -= 1
+            x.conv_cons -= 1
             g, existed = ctx.gbuf(x)
+            lazy = ctx.lazy_res.pop(id(x), None)      # (dz, bits) of the identity shortcut: added in this launch's epilogue
             wt = self.w_t(ctx, layer)
             bnb = None
             if x.cons == 0 and x.bn_src is not None and self.fuse_bn_stats:
@@ -341,7 +355,12 @@ class Engine(object):
                                ar.grad_seg(bn_layer.weight) if bn_layer.weight.requires_grad else None,
                                ar.grad_seg(bn_layer.bias) if bn_layer.bias.requires_grad else None)
                     bnb = (by, x if (relu and has_res) else None, st, relu, fin)
-            _, part = ops.conv_forward(dy, wt, I, R, S, stride, pad, mode=1, out_hw=(x.H, x.W), cin=wt.shape[3], out=g, accumulate=existed, bnb=bnb)
+            if lazy is not None:
+                assert not existed
+                _, part = ops.conv_forward(dy, wt, I, R, S, stride, pad, mode=1, out_hw=(x.H, x.W), cin=wt.shape[3], out=g, bnb=bnb,
+                                           res=lazy[0], res_mode=1, res_mask=lazy[1])
+            else:
+                _, part = ops.conv_forward(dy, wt, I, R, S, stride, pad, mode=1, out_hw=(x.H, x.W), cin=wt.shape[3], out=g, accumulate=existed, bnb=bnb)
             if bnb is not None:
                 ctx.bnb[id(x)] = part
 
@@ -468,7 +487,14 @@ class Engine(object):
         dres, dres_acc = None, False
         if res is not None and res.needs_grad:
             res.cons -= 1
-            dres, dres_acc = ctx.gbuf(res)
+            if (self.defer_shortcut_grad and relu and z.mask is not None and res.cons == 1 and res.conv_cons == 1
+                    and ctx.grad_of(res) is None and dz.t.dtype == res.t.dtype and dz.t.shape == res.t.shape):
+                # identity shortcut whose only other gradient contribution is one convolution's input gradient (conv1 of this block):
+                # g = dz * (z > 0) is not written here; that launch reads dz and the mask bits (kept alive by the entry)
+                ctx.lazy_res[id(res)] = (dz, z.mask)
+                ctx.keep.append(res)
+            else:
+                dres, dres_acc = ctx.gbuf(res)
         want_dy = y.needs_grad
         dy = ops.bn_backward(dz, z, y, st, layer.weight.data, relu, train_stats,
                              dgamma=ar.grad_seg(layer.weight) if wg else None,
@@ -779,6 +805,7 @@ class Engine(object):
             self.flush_side(ctx, dev)
             gpu_op(torch.cuda.current_stream(dev).wait_stream, side)      # join: parameter gradients are complete
         ctx.grads.clear()
+        ctx.lazy_res.clear()
         ctx.keep = []
         ctx.side_keep = []
         ctx.wt.clear()

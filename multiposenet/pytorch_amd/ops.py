@@ -85,7 +85,7 @@ class Act(object):
 
     Cs (channel storage) is a multiple of 32; lanes [C, Cs) hold zeros (see include/mpn.h).
     """
-    __slots__ = ("t", "B", "H", "W", "C", "Cs", "needs_grad", "tag", "seg", "cons", "bn_src", "mask")
+    __slots__ = ("t", "B", "H", "W", "C", "Cs", "needs_grad", "tag", "seg", "cons", "bn_src", "mask", "conv_cons")
 
     def __init__(self, t, C, needs_grad=False, tag=""):
         self.t = t
@@ -96,6 +96,7 @@ class Act(object):
         self.seg = None          # (flat buffer, index) when this activation is one level of a pyramid group (alloc_seg)
         self.cons = 0            # gradient contributions still to come in backward (engine: last-contributor detection)
         self.bn_src = None       # (y, BNState, relu, has_residual) when this is the output of a BatchNorm
+        self.conv_cons = 0       # how many of the pending contributions are input gradients of plain convolutions (engine.conv)
         self.mask = None         # sign bits of this tensor (uint8 [P, Cs / V]) when bn_act produced them for the backward pass
 
     @staticmethod
@@ -300,7 +301,7 @@ def conv_out_hw(H, W, R, S, stride, pad):
 
 def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, res=None, res_mode=0,
                  want_stats=False, out_f32=False, out=None, accumulate=False, mode=0, out_hw=None,
-                 cin=None, x_geom=None, y_geom=None, cout_store=None, needs_grad=False, tag="", bnb=None, bn_fin=None):
+                 cin=None, x_geom=None, y_geom=None, cout_store=None, needs_grad=False, tag="", bnb=None, bn_fin=None, res_mask=None):
     """Implicit-GEMM convolution.  x: Act.  w: compute-dtype tensor laid out [Cout][R][S][Cin].
 
     mode 0 = forward gather, mode 1 = dgrad gather (then ``out_hw`` is the input-gradient size and
@@ -350,6 +351,9 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         p.res_mode = res_mode
         p.res_sB, p.res_sP = res.H * res.W * res.Cs, res.Cs
         p.res_H, p.res_W = res.H, res.W
+        if res_mask is not None:          # residual * mask bits (bn_act(want_mask=True) layout): res_mode 1 only
+            assert res_mode == 1
+            p.res_mask = res_mask.data_ptr()
     stats = None
     keep = None
     if want_stats:
@@ -552,6 +556,13 @@ def bn_act(y, st, relu, res=None, needs_grad=False, tag="", want_mask=False):
     call("mpn_bn_act_forward", ptr(y.t), ptr(res.t) if res is not None else None, ptr(z.t), ptr(st.scale), ptr(st.shift),
          y.P, y.C, y.Cs, 1 if relu else 0, dtype_code(y.t.dtype), ptr(z.mask), stream_ptr())
     return z
+
+
+def masked_copy(dz, mask_bits, out):
+    """out = dz * mask (mask bits in bn_act's layout): the shortcut gradient of relu(bn(.) + shortcut), materialised."""
+    call("mpn_bn_bwd_apply", ptr(dz.t), None, None, None, None, None, None, None, None, ptr(out.t), 0, dz.P, dz.C, dz.Cs, 1,
+         dtype_code(dz.t.dtype), ptr(mask_bits), stream_ptr())
+    return out
 
 
 def bn_backward(dz, z, y, st, gamma, relu, train, dgamma=None, dbeta=None, want_dy=True, dres=None, dres_acc=False, remask=False,

@@ -418,8 +418,8 @@ def test_relu_mask_bits_replace_z_in_both_backward_passes(dtype):
     anno = t(weightgen.gen_boxes_gt(802, Bn, S)).cuda()
     bn_state = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
     outs = []
-    for on in (False, True):
-        m._engine.bn_mask_bits = on
+    for on, defer in ((False, False), (True, False), (True, True)):
+        m._engine.bn_mask_bits, m._engine.defer_shortcut_grad = on, defer
         m.load_state_dict(bn_state, strict=False)
         m._arena.ensure_grads()
         m._arena.grad_flat.zero_()
@@ -428,6 +428,9 @@ def test_relu_mask_bits_replace_z_in_both_backward_passes(dtype):
         loss.backward()
         torch.cuda.synchronize()
         outs.append((loss.detach().clone(), m._arena.grad_flat.clone()))
-    m._engine.bn_mask_bits = True
+    m._engine.bn_mask_bits = m._engine.defer_shortcut_grad = True
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "mask bits changed the gradients"
-    report("ReLU mask bits (%s): bits == (z > 0); train step bit-identical with z replaced by its sign bits in backward" % str(dtype))
+    # ... and with the identity-shortcut gradient dz * (z > 0) never materialised (conv1's dgrad epilogue adds it from dz and the bits)
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1]), "deferred shortcut gradient changed the gradients"
+    report("ReLU mask bits (%s): bits == (z > 0); train step bit-identical with z replaced by its sign bits in backward and with the "
+           "shortcut gradient folded into conv1's input-gradient launch" % str(dtype))
