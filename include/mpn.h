@@ -95,6 +95,20 @@ typedef struct MpnConvParams {
      * fin_dbeta += , fin_out = [3][Cout] k1, k2, k3 with fin_train selecting batch-statistics or frozen coefficients; mean /
      * invstd are bnb_mean / bnb_invstd).  fin_counters: one zeroed uint32 per output-channel tile (>= 64 entries cover every
      * shape); the launch leaves them zero again.  Launches sharing a counter array must be ordered (one stream).           */
+    /* Virtual channel concatenation of the gathered operand (kseg_n > 0; 3x3 / stride 1 / pad 1 launches with 16-bit operands):
+     * the input is cat_s(nearest_upsample(kseg_x[s])) over kseg_n <= 4 segments of kseg_c channels each (Cin = kseg_n * kseg_c) —
+     * torch.cat((up8(q5), up4(q4), up2(q3), q2), 1) feeding conv2 (network/posenet.py:311-315) — and is never materialised:
+     * segment s is the dense tensor [B][H >> kseg_shift[s]][W >> kseg_shift[s]][kseg_c] and pixel (h, w) of the virtual input reads
+     * its pixel (h >> shift, w >> shift).  H, W are the virtual (output) size; x, x_sB, x_sH, x_sW are ignored.            */
+    int32_t kseg_n, kseg_c;
+    int32_t kseg_shift[4];
+    const void* kseg_x[4];
+    /* Split output (y2 != NULL; plain stores only: no residual / accumulate / statistics): output channels >= y2_c0 go to the
+     * dense tensor y2[pixel * y2_sP + (channel - y2_c0)] instead of y — the input gradient of conv2 written straight into the
+     * gradient of the concatenation's full-resolution member (q2) while the up-sampled members' slices stay in y.          */
+    void* y2;
+    int64_t y2_sP;
+    int32_t y2_c0;
     uint32_t* fin_counters;
     const float* fin_gamma;
     const float* fin_beta;
@@ -134,6 +148,9 @@ int mpn_conv_pw_supported(const MpnConvParams* p);
 int mpn_conv_pw_selected(const MpnConvParams* p);
 int mpn_conv_pw_set_min_tiles(int tiles);
 int mpn_conv_pw_forward(const MpnConvParams* p, void* stream);
+/* tools/pw_timeline.py only: device buffer [workgroups][waves][8] of uint64 that the following conv_pw_kernel launches fill with
+ * s_memtime stamps at their phase boundaries (start, tile landed, then per strip: main loop done, stores issued); NULL = off */
+int mpn_conv_pw_debug_stamps(void* buf);
 
 typedef struct MpnWgradParams {
     const void* x;        /* forward input activations (gathered)                                 */
@@ -161,6 +178,11 @@ typedef struct MpnWgradParams {
     int32_t seg_chunk_pixels;
     const void* seg_x[5];
     const void* seg_dy[5];
+    /* Virtual channel concatenation of x (see MpnConvParams.kseg_*): LDS-DMA kernel with 128-channel cin tiles, kseg_c == 128 —
+     * every workgroup's cin tile is one segment.  H, W are the virtual size; x, x_sB, x_sH, x_sW are ignored.              */
+    int32_t kseg_n, kseg_c;
+    int32_t kseg_shift[4];
+    const void* kseg_x[4];
 } MpnWgradParams;
 
 int mpn_conv_wgrad_chunks(const MpnWgradParams* p);

@@ -39,6 +39,8 @@ class ConvParams(ctypes.Structure):
         ("seg_x", ctypes.c_void_p * 5), ("seg_y", ctypes.c_void_p * 5),
         ("bnb_y", ctypes.c_void_p), ("bnb_z", ctypes.c_void_p), ("bnb_mask", ctypes.c_void_p), ("bnb_mean", ctypes.c_void_p), ("bnb_invstd", ctypes.c_void_p),
         ("bnb_scale", ctypes.c_void_p), ("bnb_shift", ctypes.c_void_p), ("bnb_partial", ctypes.c_void_p), ("bnb_relu", ctypes.c_int32),
+        ("kseg_n", ctypes.c_int32), ("kseg_c", ctypes.c_int32), ("kseg_shift", ctypes.c_int32 * 4), ("kseg_x", ctypes.c_void_p * 4),
+        ("y2", ctypes.c_void_p), ("y2_sP", ctypes.c_int64), ("y2_c0", ctypes.c_int32),
         ("fin_counters", ctypes.c_void_p), ("fin_gamma", ctypes.c_void_p), ("fin_beta", ctypes.c_void_p), ("fin_rm", ctypes.c_void_p),
         ("fin_rv", ctypes.c_void_p), ("fin_out", ctypes.c_void_p), ("fin_dgamma", ctypes.c_void_p), ("fin_dbeta", ctypes.c_void_p),
         ("fin_count", ctypes.c_double), ("fin_momentum", ctypes.c_float), ("fin_eps", ctypes.c_float), ("fin_train", ctypes.c_int32),
@@ -56,6 +58,7 @@ class WgradParams(ctypes.Structure):
         ("db", ctypes.c_void_p), ("db_ws", ctypes.c_void_p),
         ("nseg", ctypes.c_int32), ("seg_H", ctypes.c_int32 * 5), ("seg_W", ctypes.c_int32 * 5), ("seg_chunk0", ctypes.c_int32 * 6),
         ("seg_chunk_pixels", ctypes.c_int32), ("seg_x", ctypes.c_void_p * 5), ("seg_dy", ctypes.c_void_p * 5),
+        ("kseg_n", ctypes.c_int32), ("kseg_c", ctypes.c_int32), ("kseg_shift", ctypes.c_int32 * 4), ("kseg_x", ctypes.c_void_p * 4),
     ]
 
 
@@ -76,6 +79,7 @@ SIGNATURES = {
     "mpn_conv_pw_selected": (_i, [_PC]),
     "mpn_conv_pw_set_min_tiles": (_i, [_i]),
     "mpn_conv_pw_forward": (_i, [_PC, _vp]),
+    "mpn_conv_pw_debug_stamps": (_i, [_vp]),
     "mpn_conv_tile_rows": (_i, [_PC]),
     "mpn_conv_shared_tile": (_i, [_PC]),
     "mpn_conv_forward": (_i, [_PC, _vp]),

@@ -387,11 +387,13 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
         for (int k0 = 0; k0 < NIT; k0 += G) {
             bool live[G];
             long yo[G];
+            unsigned pixs[G];
             u32x4_t l_res[G], l_acc[G], l_y[G], l_z[G];
             unsigned l_m[G], l_rm[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 live[g] = pix < P && ccol < p.Cout_store && !(dbg & 128);
+                pixs[g] = pix;
                 yo[g] = (long)b * p.y_sB + (long)rem * p.y_sP + ccol;
                 if (GENERAL && live[g]) {
                     if (p.res_mode != 0) {
@@ -443,7 +445,10 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                     }
                     a.store(reinterpret_cast<OT*>(&v));
                 }
-                *reinterpret_cast<u32x4_t*>(Y + yo[g]) = v;
+                if (GENERAL && pk.y2 && ccol >= pk.y2_c0)       // split output: channels >= y2_c0 live in their own dense tensor
+                    *reinterpret_cast<u32x4_t*>((OT*)pk.y2 + (long)pixs[g] * pk.y2_sP + (ccol - pk.y2_c0)) = v;
+                else
+                    *reinterpret_cast<u32x4_t*>(Y + yo[g]) = v;
                 if (bnb) {
                     Vec16<OT> dzv, yy, zz;
                     dzv.load(reinterpret_cast<const OT*>(&v));                  // the value as stored
@@ -738,16 +743,20 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
     }
     // pixel-tile DMA units: LDS row i holds input pixel (linear index) p0 - 1 + i of the line the current kernel row selects
     unsigned b_base[LB];
-    int b_h[LB];
+    int b_h[LB], b_w[LB], b_bi[LB];
     bool b_ok[LB];
+    const bool vcat = pk.kseg_n > 0;                              // virtual channel concatenation of up-sampled sources (mpn.h: kseg_*)
 #pragma unroll
     for (int q = 0; q < LB; ++q) {
         const int i = ((int)wave_u * LB + q) * 16 + u_row;
         const long pc = p0 - 1 + i;
         const bool ok = i < TP + 2 && pc >= 0 && pc < (long)P;
         const unsigned pcu = ok ? (unsigned)pc : 0u;
-        const unsigned rem = pcu % HoWo;
+        const unsigned bi = pcu / HoWo;
+        const unsigned rem = pcu - bi * HoWo;
         b_h[q] = (int)(rem / (unsigned)p.Wo);
+        b_w[q] = (int)(rem - (unsigned)b_h[q] * (unsigned)p.Wo);
+        b_bi[q] = (int)bi;
         b_ok[q] = ok;
         b_base[q] = (unsigned)(((long)pcu * p.x_sW + u_piece * C::V) * TS);
     }
@@ -793,13 +802,30 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
     };
     auto issue_b = [&](unsigned slot) {
         const int dy = (p.mode == 0) ? br - 1 : 1 - br;           // input line relative to the output line
-        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)bcc * TS));
         const unsigned st = lds_base + A_RING + slot * B_BYTES;
+        if (vcat) {
+            // channel chunk bcc lives in segment sg = bcc / kseg_c: a dense [B][H >> sh][W >> sh][kseg_c] tensor read at (h >> sh, w >> sh)
+            const int sg = __builtin_amdgcn_readfirstlane(bcc / pk.kseg_c);
+            const int sh = __builtin_amdgcn_readfirstlane(pk.kseg_shift[sg]);
+            const int Hs = p.H >> sh, Ws = p.W >> sh;
+            const i32x4_t rs = make_rsrc(pk.kseg_x[sg], (unsigned)((long)p.B * Hs * Ws * pk.kseg_c * TS));
+            const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(bcc - sg * pk.kseg_c) * TS));
 #pragma unroll
-        for (int q = 0; q < LB; ++q) {
-            const bool ok = b_ok[q] && (unsigned)(b_h[q] + dy) < (unsigned)p.H;
-            const unsigned voff = ok ? (unsigned)((int)b_base[q] + dy * line_b) : x_bytes;
-            lds_dma16(voff, rsrc_x, so, __builtin_amdgcn_readfirstlane(st + (wave_u * LB + q) * 1024u));
+            for (int q = 0; q < LB; ++q) {
+                const int hh = b_h[q] + dy;
+                const bool ok = b_ok[q] && (unsigned)hh < (unsigned)p.H;
+                const unsigned src = (unsigned)((b_bi[q] * Hs + (hh >> sh)) * Ws + (b_w[q] >> sh));
+                const unsigned voff = ok ? (src * (unsigned)pk.kseg_c + (unsigned)(u_piece * C::V)) * TS : 0x80000000u;
+                lds_dma16(voff, rs, so, __builtin_amdgcn_readfirstlane(st + (wave_u * LB + q) * 1024u));
+            }
+        } else {
+            const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)bcc * TS));
+#pragma unroll
+            for (int q = 0; q < LB; ++q) {
+                const bool ok = b_ok[q] && (unsigned)(b_h[q] + dy) < (unsigned)p.H;
+                const unsigned voff = ok ? (unsigned)((int)b_base[q] + dy * line_b) : x_bytes;
+                lds_dma16(voff, rsrc_x, so, __builtin_amdgcn_readfirstlane(st + (wave_u * LB + q) * 1024u));
+            }
         }
         bcc += C::KC;
         if (bcc == p.Cin) { bcc = 0; ++br; }
@@ -885,7 +911,7 @@ inline int pick_tc(const MpnConvParams& p, long tilesP) {
 inline bool conv_uses_s3(const MpnConvParams& p, int tc) {
     static const bool on = !(getenv("MPN_IGEMM_S3") && atoi(getenv("MPN_IGEMM_S3")) == 0);
     if (!on || p.dtype == MPN_F32 || p.R != 3 || p.S != 3 || p.stride != 1 || p.pad != 1 || tc < 64) return false;
-    if (p.nseg > 0) return true;                                  // pyramid levels are dense by construction
+    if (p.nseg > 0 || p.kseg_n > 0) return true;                  // pyramid levels / concatenation members are dense by construction
     return p.H == p.Ho && p.W == p.Wo && p.x_sH == (int64_t)p.W * p.x_sW && p.x_sB == (int64_t)p.H * p.x_sH;
 }
 
@@ -916,7 +942,7 @@ int launch_conv(const MpnConvParams& p, hipStream_t st) {
     if (grid <= 0 || grid > 0x7fffffffL || P >= 0x7fffffffL) return MPN_E_BADARG;
     static const int dbg = getenv("MPN_DEBUG_FLAGS") ? atoi(getenv("MPN_DEBUG_FLAGS")) : 0;   // microbenchmark ablations only
     // "plain" = conv (+ BN tile statistics): no per-element epilogue math at all, lighter register footprint
-    const bool general = p.scale || p.bias || p.res_mode || p.accumulate || p.act || (p.Cout % tc) != 0 || p.bnb_partial;
+    const bool general = p.scale || p.bias || p.res_mode || p.accumulate || p.act || (p.Cout % tc) != 0 || p.bnb_partial || p.y2;
     return general ? launch_conv_k<T, OUTF32, true>(p, tc, grid, dbg, st) : launch_conv_k<T, OUTF32, false>(p, tc, grid, dbg, st);
 }
 
@@ -953,8 +979,19 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
             MPN_CHECK_ARG(p.seg_tile0[l + 1] - p.seg_tile0[l] == tiles);
         }
     } else {
-        MPN_CHECK_ARG(p.x && p.y && p.Ho > 0 && p.Wo > 0 && p.H > 0 && p.W > 0);
+        MPN_CHECK_ARG((p.x || p.kseg_n > 0) && p.y && p.Ho > 0 && p.Wo > 0 && p.H > 0 && p.W > 0);
     }
+    if (p.kseg_n > 0) {     // virtual concatenation: served by the shared-tile 3x3 kernel only
+        MPN_CHECK_ARG(p.kseg_n <= 4 && p.kseg_c > 0 && p.kseg_c % 32 == 0 && p.Cin == p.kseg_n * p.kseg_c && p.mode == 0 && !p.nseg);
+        MPN_CHECK_ARG(p.dtype != MPN_F32 && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.H == p.Ho && p.W == p.Wo && p.Cout_store > 32);
+        for (int k = 0; k < p.kseg_n; ++k) {
+            MPN_CHECK_ARG(p.kseg_x[k] && p.kseg_shift[k] >= 0 && p.kseg_shift[k] < 8 && ((p.H >> p.kseg_shift[k]) << p.kseg_shift[k]) == p.H &&
+                          ((p.W >> p.kseg_shift[k]) << p.kseg_shift[k]) == p.W);
+            if ((int64_t)p.B * (p.H >> p.kseg_shift[k]) * (p.W >> p.kseg_shift[k]) * p.kseg_c * 2 >= 0x7ffffff0LL) return MPN_E_UNSUPPORTED;
+        }
+    }
+    MPN_CHECK_ARG(!p.y2 || (p.y2_c0 > 0 && p.y2_c0 % 8 == 0 && p.y2_c0 < p.Cout_store && p.y2_sP >= p.Cout_store - p.y2_c0 && !p.res_mode &&
+                            !p.accumulate && !p.stats && !p.bnb_partial && !p.nseg && !p.out_f32));
     MPN_CHECK_ARG(p.w && p.B > 0);
     MPN_CHECK_ARG(mpn_dtype_ok(p.dtype));
     const int kc = p.dtype == MPN_F32 ? 16 : 32;

@@ -75,11 +75,16 @@ constexpr int PW_LDS = PW_TP * 256 * 2;
 //   2  accumulate onto the existing output AND BatchNorm-backward tile statistics with the ReLU mask taken from z: the training input
 //      gradient of conv1 (the block below ends in relu(bn3(.) + shortcut)).
 template <typename T, int NW, int EPI>
-__global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const MpnConvParams p, const int dbg) {
+__global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const MpnConvParams p, const int dbg, unsigned long long* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[PW_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tp = blockIdx.x;
+    // tools/pw_timeline.py: s_memtime stamps per wave at the phase boundaries (null in production launches)
+    unsigned long long* my_stamps = stamps ? stamps + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8 : nullptr;
+    int stamp_i = 0;
+    auto stamp = [&]() { if (my_stamps && lane == 0 && stamp_i < 8) my_stamps[stamp_i] = __builtin_readcyclecounter(); ++stamp_i; };
+    stamp();
     const unsigned P = (unsigned)p.B * (unsigned)p.Ho * (unsigned)p.Wo;
     const unsigned p0 = (unsigned)tp * PW_TP;
     const int K = p.Cin;
@@ -133,6 +138,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const MpnConvParams
     if (strip < strip_end) load_a(a0, strip, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                            // the pixel tile is complete and read-only from here on
+    stamp();
 
     T* __restrict__ Y = (T*)p.y;
     // Waves w and w + NW/2 share a SIMD (a workgroup's waves are dealt to the SIMDs cyclically).  With equal priority both halves run
@@ -168,6 +174,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const MpnConvParams
             load_a(a0, more ? strip : nxt_strip, more ? ks + 2 : 0);
             step(a1, ks + 1);
         }
+        stamp();
         const int cb = strip * 64;
 
         // ---- epilogue of the strip: lane = 8 consecutive channels (cb + m*32 + G*8 ..) of pixel p0 + j*16 + r16 ----------------
@@ -299,6 +306,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const MpnConvParams
                 }
             }
         }
+        stamp();
         if (part) {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -316,6 +324,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const MpnConvParams
 }
 
 int g_pw_min_tiles = -1;
+unsigned long long* g_pw_stamps = nullptr;
 
 inline int pw_min_tiles() {
     if (g_pw_min_tiles < 0) g_pw_min_tiles = getenv("MPN_PW_MIN_TILES") ? atoi(getenv("MPN_PW_MIN_TILES")) : 96;
@@ -355,13 +364,13 @@ int pw_launch(const MpnConvParams& p, hipStream_t st) {
     const unsigned gy = cfg == 2 ? 1u : (unsigned)(nstrips / nw);
     const dim3 g(grid, gy);
     if (nw == 8) {
-        if (epi == 2) hipLaunchKernelGGL((conv_pw_kernel<T, 8, 2>), g, dim3(512), 0, st, p, dbg);
-        else if (epi == 1) hipLaunchKernelGGL((conv_pw_kernel<T, 8, 1>), g, dim3(512), 0, st, p, dbg);
-        else hipLaunchKernelGGL((conv_pw_kernel<T, 8, 0>), g, dim3(512), 0, st, p, dbg);
+        if (epi == 2) hipLaunchKernelGGL((conv_pw_kernel<T, 8, 2>), g, dim3(512), 0, st, p, dbg, g_pw_stamps);
+        else if (epi == 1) hipLaunchKernelGGL((conv_pw_kernel<T, 8, 1>), g, dim3(512), 0, st, p, dbg, g_pw_stamps);
+        else hipLaunchKernelGGL((conv_pw_kernel<T, 8, 0>), g, dim3(512), 0, st, p, dbg, g_pw_stamps);
     } else {
-        if (epi == 2) hipLaunchKernelGGL((conv_pw_kernel<T, 4, 2>), g, dim3(256), 0, st, p, dbg);
-        else if (epi == 1) hipLaunchKernelGGL((conv_pw_kernel<T, 4, 1>), g, dim3(256), 0, st, p, dbg);
-        else hipLaunchKernelGGL((conv_pw_kernel<T, 4, 0>), g, dim3(256), 0, st, p, dbg);
+        if (epi == 2) hipLaunchKernelGGL((conv_pw_kernel<T, 4, 2>), g, dim3(256), 0, st, p, dbg, g_pw_stamps);
+        else if (epi == 1) hipLaunchKernelGGL((conv_pw_kernel<T, 4, 1>), g, dim3(256), 0, st, p, dbg, g_pw_stamps);
+        else hipLaunchKernelGGL((conv_pw_kernel<T, 4, 0>), g, dim3(256), 0, st, p, dbg, g_pw_stamps);
     }
     return mpn_launch_status();
 }
@@ -387,6 +396,9 @@ extern "C" int mpn_conv_pw_set_min_tiles(int tiles) {
     if (tiles >= 0) g_pw_min_tiles = tiles;
     return old;
 }
+
+// tools only: device buffer of [workgroups][waves][8] s_memtime stamps written by the next launches (nullptr = off)
+extern "C" int mpn_conv_pw_debug_stamps(void* buf) { g_pw_stamps = (unsigned long long*)buf; return 0; }
 
 extern "C" int mpn_conv_pw_supported(const MpnConvParams* p) { return p && pw_shape_ok(*p) ? 1 : 0; }
 

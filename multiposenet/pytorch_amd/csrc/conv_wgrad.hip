@@ -384,6 +384,18 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, lo
     const long k_begin = (long)chunk_local * chunk_pixels;
     long k_end = k_begin + chunk_pixels; if (k_end > P) k_end = P;
     const int dy_cs = ((p.Cout + 31) / 32) * 32;
+    // virtual channel concatenation of x (mpn.h: kseg_*): this workgroup's cin tile is ONE member — a dense, nearest-up-sampled
+    // tensor of kseg_c channels read at (hi >> vsh, wi >> vsh)
+    int vsh = 0, vc0 = 0;
+    if (!SEG && pk.kseg_n > 0) {
+        const int sg = rfl(m0 / pk.kseg_c);
+        vsh = rfl(pk.kseg_shift[sg]);
+        vc0 = sg * pk.kseg_c;
+        p.x = rfl_ptr(pk.kseg_x[sg]);
+        p.x_sW = pk.kseg_c;
+        p.x_sH = (int64_t)(p.W >> vsh) * p.x_sW;
+        p.x_sB = (int64_t)(p.H >> vsh) * p.x_sH;
+    }
 
     const i32x4_t rsrc_x = make_rsrc(p.x, (unsigned)((long)p.B * p.x_sB * 2));
     const i32x4_t rsrc_dy = make_rsrc(p.dy, (unsigned)((k_end > k_begin ? k_end : 0) * (long)p.dy_sP * 2));
@@ -424,8 +436,8 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, lo
         for (int q = 0; q < QA; ++q) {
             const int hi = a_px[q].ho * p.stride - p.pad + r, wi = a_px[q].wo * p.stride - p.pad + s;
             const bool ok = a_on[q] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const unsigned off = ((unsigned)a_px[q].b * (unsigned)p.x_sB + (unsigned)hi * (unsigned)p.x_sH +
-                                  (unsigned)wi * (unsigned)p.x_sW + (unsigned)a_chan[q]) * 2u;
+            const unsigned off = ((unsigned)a_px[q].b * (unsigned)p.x_sB + (unsigned)(hi >> vsh) * (unsigned)p.x_sH +
+                                  (unsigned)(wi >> vsh) * (unsigned)p.x_sW + (unsigned)(a_chan[q] - vc0)) * 2u;
             lds_dma16(ok ? off : DMA_OOB, rsrc_x, 0u, __builtin_amdgcn_readfirstlane(st + (wave_u * QA + q) * 1024u));
             a_px[q].advance_digits(adv_b, adv_h, adv_w, p.Ho, p.Wo);
         }
@@ -610,6 +622,7 @@ inline long wgrad_total_pixels(const MpnWgradParams& p) {
 inline bool wgrad_uses_dma(const MpnWgradParams& p) {
     static const bool use_dma = !(getenv("MPN_WGRAD_NO_DMA") && atoi(getenv("MPN_WGRAD_NO_DMA")));
     long P = (long)p.B * p.Ho * p.Wo, xb = (long)p.B * p.x_sB;
+    if (p.kseg_n > 0) xb = (long)p.B * p.H * p.W * p.kseg_c;
     if (p.nseg > 0) {
         P = 0; xb = 0;
         for (int l = 0; l < p.nseg; ++l) {
@@ -736,7 +749,15 @@ extern "C" int mpn_conv_wgrad(const MpnWgradParams* pp, void* stream) {
         MPN_CHECK_ARG(p.seg_chunk_pixels > 0 && p.seg_chunk_pixels % 32 == 0 && p.seg_chunk0[0] == 0 && p.seg_chunk0[p.nseg] == p.chunks);
         for (int l = 0; l < p.nseg; ++l) MPN_CHECK_ARG(p.seg_x[l] && p.seg_dy[l] && p.seg_H[l] > 0 && p.seg_W[l] > 0);
     } else {
-        MPN_CHECK_ARG(p.x && p.dy && p.Ho > 0 && p.Wo > 0);
+        MPN_CHECK_ARG((p.x || p.kseg_n > 0) && p.dy && p.Ho > 0 && p.Wo > 0);
+    }
+    if (p.kseg_n > 0) {
+        int tm, tn;
+        wgrad_tiles(p, tm, tn);
+        MPN_CHECK_ARG(p.kseg_n <= 4 && p.kseg_c == 128 && tm == 128 && p.Cin == p.kseg_n * p.kseg_c && wgrad_uses_dma(p) && p.stride == 1);
+        for (int k = 0; k < p.kseg_n; ++k)
+            MPN_CHECK_ARG(p.kseg_x[k] && p.kseg_shift[k] >= 0 && p.kseg_shift[k] < 8 && ((p.H >> p.kseg_shift[k]) << p.kseg_shift[k]) == p.H &&
+                          ((p.W >> p.kseg_shift[k]) << p.kseg_shift[k]) == p.W);
     }
     MPN_CHECK_ARG(p.Cin % 8 == 0);
     MPN_CHECK_ARG(p.chunks >= 1 && (p.chunks == 1 || p.ws));
@@ -750,7 +771,7 @@ extern "C" int mpn_conv_wgrad(const MpnWgradParams* pp, void* stream) {
 extern "C" int mpn_conv_wgrad_partials(const MpnWgradParams* pp, void* stream) {
     if (!pp) return MPN_E_BADARG;
     const MpnWgradParams& p = *pp;
-    MPN_CHECK_ARG(p.dw && p.ws && p.chunks > 1 && (p.nseg > 0 || (p.x && p.dy && p.Ho > 0 && p.Wo > 0)));
+    MPN_CHECK_ARG(p.dw && p.ws && p.chunks > 1 && (p.nseg > 0 || ((p.x || p.kseg_n > 0) && p.dy && p.Ho > 0 && p.Wo > 0)));
     MPN_CHECK_ARG(mpn_dtype_ok(p.dtype));
     MPN_CHECK_ARG(p.B > 0 && p.Cin > 0 && p.Cout > 0 && p.Cin % 8 == 0);
     hipStream_t st = (hipStream_t)stream;

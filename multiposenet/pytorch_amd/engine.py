@@ -100,6 +100,9 @@ class Engine(object):
         # ... and the shortcut gradient of an identity block, dz * (z > 0), is not written by bn_bwd_apply at all: conv1's input-gradient
         # launch (the only other contribution to that tensor) reads dz and the bits in its epilogue (MpnConvParams.res_mask)
         self.defer_shortcut_grad = os.environ.get("MPN_DEFER_SHORTCUT_GRAD", "1") != "0"
+        # torch.cat((up8(q5), up4(q4), up2(q3), q2), 1) -> conv2 (posenet.py:311-315): the 512-channel tensor is never written; conv2's
+        # forward and weight-gradient launches gather from the four members, its input gradient lands in q2's gradient directly
+        self.virtual_concat = os.environ.get("MPN_VIRTUAL_CONCAT", "1") != "0"
 
     def side_stream(self, device):
         """Second HIP stream for weight/bias gradients.  They are off the backward critical path (only the
@@ -584,6 +587,71 @@ class Engine(object):
             ctx.tape.append(bwd)
         return dst
 
+    def conv_cat(self, ctx, srcs, H, W, layer, act=0):
+        """layer(torch.cat([nearest_upsample(s) to H x W for s in srcs], 1)) for a 3x3 / stride-1 layer, the concatenation virtual
+        (ops.conv_forward_cat).  Backward: weight gradient gathers the same way; the input gradient of the full-resolution LAST
+        member is written by the dgrad launch itself (split output), the up-sampled members' slices go through one buffer of
+        their channels only and are summed down to their own resolution."""
+        O, I, R, S, stride, pad = _geom(layer)
+        bias = layer.bias
+        y = ops.conv_forward_cat(srcs, H, W, self.w_fwd(layer), O, bias=bias.data if bias is not None else None, act=act)
+        if ctx.train:
+            need_x = any(s.needs_grad for s in srcs)
+            y.needs_grad = bool(need_x or layer.weight.requires_grad or (bias is not None and bias.requires_grad))
+            if y.needs_grad:
+                self._note_use(ctx, layer.weight)
+                self._note_use(ctx, bias)
+                if need_x:
+                    self.w_t(ctx, layer)
+                ctx.tape.append(lambda: self._conv_cat_bwd(ctx, srcs, H, W, layer, y, act))
+        return y
+
+    def _conv_cat_bwd(self, ctx, srcs, H, W, layer, y, act):
+        dy = ctx.pop_grad(y)
+        O, I, R, S, stride, pad = _geom(layer)
+        bias = layer.bias
+        wg = layer.weight.requires_grad
+        bg = bias is not None and bias.requires_grad
+        if dy is None:
+            if wg:
+                self._grad_done(ctx, layer.weight)
+            if bg:
+                self._grad_done(ctx, bias)
+            return
+        if act == 1:
+            dy = ops.relu_backward(dy, y)
+        ar = self.m._arena
+        if wg or bg:
+            def param_grads():
+                done = False
+                if wg:
+                    done = ops.conv_wgrad_cat(srcs, H, W, dy, ar.grad_seg(layer.weight), O, db=ar.grad_seg(bias) if bg else None)
+                if bg and not done:
+                    ops.bias_grad(dy, ar.grad_seg(bias), O)
+            self._on_side(ctx, dy.t.device, (srcs, dy), param_grads)
+            if wg:
+                self._grad_done(ctx, layer.weight)
+            if bg:
+                self._grad_done(ctx, bias)
+        if any(s.needs_grad for s in srcs):
+            wt = self.w_t(ctx, layer)
+            last = srcs[-1]
+            direct = last.needs_grad and last.H == H and last.W == W and len(srcs) > 1
+            c0 = sum(s.Cs for s in (srcs[:-1] if direct else srcs))
+            d_rest = Act(torch.empty((dy.B, H, W, c0), dtype=dy.t.dtype, device=dy.t.device), c0)
+            g_last = Act(torch.empty_like(last.t), last.C) if direct else None
+            ops.conv_forward(dy, wt, I, R, S, 1, pad, mode=1, out_hw=(H, W), cin=wt.shape[3], out=d_rest,
+                             split=(g_last, c0) if direct else None)
+            off = 0
+            for s_ in (srcs[:-1] if direct else srcs):
+                if s_.needs_grad:
+                    g = Act(torch.empty_like(s_.t), s_.C)
+                    ops.upsample_slice_backward(d_rest, g, off)
+                    ctx.set_grad(s_, g)
+                off += s_.Cs
+            if direct:
+                ctx.set_grad(last, g_last)
+
     def export(self, ctx, src, C, Ho, Wo, slot):
         """Internal padded tensor -> exact f32 API tensor (nearest up-sampled to Ho x Wo)."""
         out = ops.export_f32(src, C, Ho, Wo)
@@ -710,8 +778,11 @@ class Engine(object):
         q4, _ = self.conv(ctx, self.conv(ctx, p4, m.convt2)[0], m.convs2)
         q3, _ = self.conv(ctx, self.conv(ctx, p3, m.convt3)[0], m.convs3)
         q2, _ = self.conv(ctx, self.conv(ctx, p2, m.convt4)[0], m.convs4)
-        cat = self.concat_up(ctx, [q5, q4, q3, q2], Ho, Wo)
-        h, _ = self.conv(ctx, cat, m.conv2, act=1)
+        if self.virtual_concat and ops.cat_supported([q5, q4, q3, q2], Ho, Wo):
+            h = self.conv_cat(ctx, [q5, q4, q3, q2], Ho, Wo, m.conv2, act=1)
+        else:
+            cat = self.concat_up(ctx, [q5, q4, q3, q2], Ho, Wo)
+            h, _ = self.conv(ctx, cat, m.conv2, act=1)
         pr, _ = self.conv(ctx, h, m.convfin, out_f32=True)
         pred = self.export(ctx, pr, 18, Ho, Wo, "pred")
         return pred, saved

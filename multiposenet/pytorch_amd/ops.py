@@ -295,13 +295,108 @@ def conv_wgrad_seg(xs, dys, dw, Cout, R, S, pad, db=None):
     return True, fused_db
 
 
+def _kseg_fill(p, srcs, H, W):
+    """Describe the virtual concatenation cat_s(nearest_upsample(srcs[s])) (MpnConvParams / MpnWgradParams kseg_*)."""
+    c = srcs[0].Cs
+    p.kseg_n, p.kseg_c = len(srcs), c
+    for i, a in enumerate(srcs):
+        sh = (H // a.H).bit_length() - 1
+        if a.Cs != c or a.C != c or (a.H << sh) != H or (a.W << sh) != W or a.B != srcs[0].B or a.t.dtype != srcs[0].t.dtype:
+            raise _lib.MpnError("virtual concatenation: member %d does not up-sample to %dx%d by a power of two" % (i, H, W))
+        p.kseg_shift[i] = sh
+        p.kseg_x[i] = a.t.data_ptr()
+
+
+def cat_supported(srcs, H, W):
+    """True when conv_forward_cat / conv_wgrad_cat serve cat(up(srcs)) at H x W: 16-bit members of 128 channels, power-of-two ratios."""
+    if not srcs or len(srcs) > 4 or not is16(srcs[0].t.dtype):
+        return False
+    for a in srcs:
+        sh = (H // max(a.H, 1)).bit_length() - 1
+        if a.C != 128 or a.Cs != 128 or (a.H << sh) != H or (a.W << sh) != W or a.t.dtype != srcs[0].t.dtype:
+            return False
+    return True
+
+
+def conv_forward_cat(srcs, H, W, w, Cout, bias=None, act=0, tag=""):
+    """3x3 / stride 1 / pad 1 convolution over torch.cat([nearest_upsample(s) for s in srcs], 1) WITHOUT materialising it
+    (posenet.py:311-315: the 512-channel input of conv2).  w: [Cout][3][3][len(srcs) * 128]."""
+    x0 = srcs[0]
+    dt, dev = x0.t.dtype, x0.t.device
+    out = Act.empty(x0.B, H, W, Cout, dt, dev, False, tag)
+    p = ConvParams()
+    _kseg_fill(p, srcs, H, W)
+    p.w, p.y = w.data_ptr(), out.t.data_ptr()
+    p.bias = bias.data_ptr() if bias is not None else None
+    p.B, p.H, p.W, p.Ho, p.Wo = x0.B, H, W, H, W
+    p.Cin, p.Cout, p.Cout_store = p.kseg_n * p.kseg_c, Cout, out.Cs
+    p.x_sW, p.x_sH, p.x_sB = p.Cin, W * p.Cin, H * W * p.Cin          # geometry of the virtual tensor (not dereferenced)
+    p.y_sB, p.y_sP = H * W * out.Cs, out.Cs
+    p.R, p.S, p.stride, p.pad = 3, 3, 1, 1
+    p.act, p.dtype = act, dtype_code(dt)
+    if KERNEL_EVENTS.on:
+        e0 = KERNEL_EVENTS.begin()
+        call("mpn_conv_forward", ctypes.byref(p), stream_ptr())
+        tc = call("mpn_conv_tile_rows", ctypes.byref(p))
+        name = "conv_igemm_s3_kernel<%s, %d, 128, false, true>" % (dtype_name(dt), tc)
+        if KERNEL_EVENTS.detail:
+            name = "fwd 3x3 %d->%d @%dx%d s1 virtual-cat%s%s|%d" % (p.Cin, Cout, H, W, " bias" if bias is not None else "", " act%d" % act if act else "",
+                                                                    sum(a.t.numel() for a in srcs) * 2 + out.t.numel() * 2)
+        KERNEL_EVENTS.end(name, 2.0 * x0.B * H * W * Cout * 9 * p.Cin, e0)
+    else:
+        call("mpn_conv_forward", ctypes.byref(p), stream_ptr())
+    return out
+
+
+def conv_wgrad_cat(srcs, H, W, dy, dw, Cout, db=None):
+    """dw += wgrad of the convolution of conv_forward_cat (x = the virtual concatenation); db fused as in conv_wgrad."""
+    x0 = srcs[0]
+    dev, dt = x0.t.device, x0.t.dtype
+    p = WgradParams()
+    _kseg_fill(p, srcs, H, W)
+    Cin = p.kseg_n * p.kseg_c
+    p.dy, p.dw = dy.t.data_ptr(), dw.data_ptr()
+    p.dy_sP = dy.Cs
+    p.x_sW, p.x_sH, p.x_sB = Cin, W * Cin, H * W * Cin
+    p.B, p.H, p.W, p.Cin = x0.B, H, W, Cin
+    p.Ho, p.Wo, p.Cout = H, W, Cout
+    p.R, p.S, p.stride, p.pad = 3, 3, 1, 1
+    p.dtype = dtype_code(dt)
+    p.chunks = 1
+    chunks = call("mpn_conv_wgrad_chunks", ctypes.byref(p))
+    p.chunks = chunks
+    if chunks > 1:
+        p.ws = workspace(chunks * Cout * 9 * Cin * 4, dev, slot=1).data_ptr()
+    fused_db = db is not None
+    if fused_db:
+        p.db = db.data_ptr()
+        if chunks > 1:
+            p.db_ws = workspace(chunks * Cout * 4, dev, slot=4).data_ptr()
+    if KERNEL_EVENTS.on:
+        kid = call("mpn_conv_wgrad_kernel_id", ctypes.byref(p))
+        e0 = KERNEL_EVENTS.begin()
+        call("mpn_conv_wgrad_partials" if chunks > 1 else "mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
+        name = "conv_wgrad_dma%s_kernel<%d, %d>" % ("_f16" if dt == torch.float16 else "", kid >> 16, (kid >> 4) & 0xfff)
+        if KERNEL_EVENTS.detail:
+            name = "wgrad 3x3 %d->%d @%dx%d s1 virtual-cat chunks=%d|%d" % (Cin, Cout, H, W, chunks, sum(a.t.numel() for a in srcs) * 2 + dy.t.numel() * 2)
+        KERNEL_EVENTS.end(name, 2.0 * x0.B * H * W * Cout * 9 * Cin, e0)
+        if chunks > 1:
+            call("mpn_reduce_partials", p.ws, chunks, Cout * 9 * Cin, p.dw, 1, stream_ptr())
+            if fused_db:
+                call("mpn_reduce_partials", p.db_ws, chunks, Cout, p.db, 1, stream_ptr())
+    else:
+        call("mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
+    return fused_db
+
+
 def conv_out_hw(H, W, R, S, stride, pad):
     return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
 
 
 def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, res=None, res_mode=0,
                  want_stats=False, out_f32=False, out=None, accumulate=False, mode=0, out_hw=None,
-                 cin=None, x_geom=None, y_geom=None, cout_store=None, needs_grad=False, tag="", bnb=None, bn_fin=None, res_mask=None):
+                 cin=None, x_geom=None, y_geom=None, cout_store=None, needs_grad=False, tag="", bnb=None, bn_fin=None, res_mask=None,
+                 split=None):
     """Implicit-GEMM convolution.  x: Act.  w: compute-dtype tensor laid out [Cout][R][S][Cin].
 
     mode 0 = forward gather, mode 1 = dgrad gather (then ``out_hw`` is the input-gradient size and
@@ -334,6 +429,13 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         p.y = yt.data_ptr()
         p.y_sB, p.y_sP = ysB, ysP
         p.Cout_store = cout_store if cout_store is not None else round_up(Cout, 4)
+    if split is not None:
+        # split=(y2 Act, c0): output channels >= c0 are written to y2 (dense, y2.Cs channels), the rest to `out` (row stride out.Cs):
+        # the launch computes c0 + y2.C channels in all
+        y2, c0 = split
+        assert y_geom is None and out.Cs >= c0 and (y2.B, y2.H, y2.W) == (x.B, Ho, Wo) and Cout == c0 + y2.C and y2.t.dtype == odt
+        p.y2, p.y2_sP, p.y2_c0 = y2.t.data_ptr(), y2.Cs, c0
+        p.Cout_store = c0 + y2.Cs
     p.x = x.t.data_ptr()
     p.w = w.data_ptr()
     p.bias = bias.data_ptr() if bias is not None else None

@@ -434,3 +434,68 @@ def test_relu_mask_bits_replace_z_in_both_backward_passes(dtype):
     assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1]), "deferred shortcut gradient changed the gradients"
     report("ReLU mask bits (%s): bits == (z > 0); train step bit-identical with z replaced by its sign bits in backward and with the "
            "shortcut gradient folded into conv1's input-gradient launch" % str(dtype))
+
+
+# ------------------------------------------------------------------------------------------------ virtual concatenation
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_virtual_concat_equals_the_materialised_concatenation(dtype):
+    """posenet.py:311-315: conv2 over torch.cat((up8(q5), up4(q4), up2(q3), q2), 1).  The 512-channel tensor is never written:
+    conv2's forward (shared-tile 3x3 kernel) and weight-gradient (LDS-DMA kernel) launches gather from the four members with the
+    nearest-neighbour index in the DMA address, the input-gradient launch writes q2's share straight into q2's gradient.  Same
+    k-order, same slices: outputs, weight / bias gradients and member gradients are bit-identical to the materialised path —
+    at kernel level on odd sizes, and for a whole training step (loss, every gradient)."""
+    from multiposenet.pytorch_amd import ops
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    from oracle import weightgen
+    dev = "cuda"
+    g = torch.Generator().manual_seed(11)
+    for (B, H, W) in ((2, 24, 40), (1, 8, 8), (3, 16, 24)):
+        srcs = [ops.Act((torch.randn(B, H >> sh, W >> sh, 128, generator=g) * 0.5).to(dtype).to(dev), 128) for sh in (3, 2, 1, 0)]
+        w = (torch.randn(256, 3, 3, 512, generator=g) * 0.02).to(dtype).to(dev)
+        bias = torch.randn(256, generator=g).to(dev)
+        cat = ops.Act(torch.empty(B, H, W, 512, dtype=dtype, device=dev), 512)
+        for i, a in enumerate(srcs):
+            ops.upsample_slice(a, cat, i * 128)
+        y_ref, _ = ops.conv_forward(cat, w, 256, 3, 3, 1, 1, bias=bias, act=1)
+        y_vir = ops.conv_forward_cat(srcs, H, W, w, 256, bias=bias, act=1)
+        assert torch.equal(y_ref.t.view(torch.int16), y_vir.t.view(torch.int16)), "virtual-concat forward differs at %dx%dx%d" % (B, H, W)
+        dy = ops.Act((torch.randn(B, H, W, 256, generator=g) * 0.1).to(dtype).to(dev), 256)
+        dw_ref = torch.zeros(256 * 9 * 512, device=dev); db_ref = torch.zeros(256, device=dev)
+        dw_vir = torch.zeros_like(dw_ref); db_vir = torch.zeros_like(db_ref)
+        assert ops.conv_wgrad(cat, dy, dw_ref, 256, 3, 3, 1, 1, db=db_ref) and ops.conv_wgrad_cat(srcs, H, W, dy, dw_vir, 256, db=db_vir)
+        assert torch.equal(dw_ref, dw_vir) and torch.equal(db_ref, db_vir), "virtual-concat weight gradient differs"
+        # input gradient: one 512-channel buffer vs 384-channel buffer + direct q2 gradient
+        wt = torch.zeros(512, 3, 3, 256, dtype=dtype, device=dev)
+        ops.weight_transpose(w.float(), wt, 256, 9, 512, 256)
+        d_full = ops.Act(torch.empty(B, H, W, 512, dtype=dtype, device=dev), 512)
+        ops.conv_forward(dy, wt, 512, 3, 3, 1, 1, mode=1, out_hw=(H, W), cin=256, out=d_full)
+        d_rest = ops.Act(torch.empty(B, H, W, 384, dtype=dtype, device=dev), 384)
+        g_q2 = ops.Act(torch.empty(B, H, W, 128, dtype=dtype, device=dev), 128)
+        ops.conv_forward(dy, wt, 512, 3, 3, 1, 1, mode=1, out_hw=(H, W), cin=256, out=d_rest, split=(g_q2, 384))
+        assert torch.equal(d_full.t[..., :384].contiguous().view(torch.int16), d_rest.t.view(torch.int16))
+        assert torch.equal(d_full.t[..., 384:].contiguous().view(torch.int16), g_q2.t.view(torch.int16))
+    if dtype != torch.bfloat16:
+        return
+    m = get_model(50, dtype)
+    for p in m.prn.parameters():
+        p.requires_grad = False
+    m.train()
+    Bn, S = 2, 128
+    img = t(weightgen.gen_images(810, Bn, S, S)).cuda()
+    heat, wgt = (t(a).cuda() for a in weightgen.gen_keypoint_gt(811, Bn, S // 4, S // 4))
+    bn_state = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
+    outs = []
+    for virt in (False, True):
+        m._engine.virtual_concat = virt
+        m.load_state_dict(bn_state, strict=False)
+        m._arena.ensure_grads()
+        m._arena.grad_flat.zero_()
+        pred, saved = m([img, "keypoint_subnet"])
+        loss, _ = poseNet.build_loss(saved, "keypoint_subnet", heat, wgt)
+        loss.backward()
+        torch.cuda.synchronize()
+        outs.append((pred.detach().clone(), loss.detach().clone(), m._arena.grad_flat.clone()))
+    m._engine.virtual_concat = True
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), "virtual concatenation changed the training step"
+    report("virtual concatenation (conv2 of the keypoint head): forward / weight gradient / input gradient bit-identical to the "
+           "materialised 512-channel tensor; whole keypoint step bit-identical")
