@@ -109,6 +109,12 @@ typedef struct MpnConvParams {
     void* y2;
     int64_t y2_sP;
     int32_t y2_c0;
+    /* ReLU-backward mask in the epilogue (input-gradient launches): the tensor this launch writes is the gradient w.r.t. a tensor
+     * t = relu(.) produced by a convolution with act 1 (the RetinaNet towers, posenet.py:48-66,91-109; conv2, :313); the consumer
+     * needs d(pre-activation) = gradient * (t > 0).  relu_y = t (geometry / element type / strides of y; pyramid mode: seg_ry[l]):
+     * the stored result is zeroed where t <= 0, which replaces a separate mpn_relu_backward pass over the tensor.            */
+    const void* relu_y;
+    const void* seg_ry[5];
     uint32_t* fin_counters;
     const float* fin_gamma;
     const float* fin_beta;

@@ -41,6 +41,7 @@ class ConvParams(ctypes.Structure):
         ("bnb_scale", ctypes.c_void_p), ("bnb_shift", ctypes.c_void_p), ("bnb_partial", ctypes.c_void_p), ("bnb_relu", ctypes.c_int32),
         ("kseg_n", ctypes.c_int32), ("kseg_c", ctypes.c_int32), ("kseg_shift", ctypes.c_int32 * 4), ("kseg_x", ctypes.c_void_p * 4),
         ("y2", ctypes.c_void_p), ("y2_sP", ctypes.c_int64), ("y2_c0", ctypes.c_int32),
+        ("relu_y", ctypes.c_void_p), ("seg_ry", ctypes.c_void_p * 5),
         ("fin_counters", ctypes.c_void_p), ("fin_gamma", ctypes.c_void_p), ("fin_beta", ctypes.c_void_p), ("fin_rm", ctypes.c_void_p),
         ("fin_rv", ctypes.c_void_p), ("fin_out", ctypes.c_void_p), ("fin_dgamma", ctypes.c_void_p), ("fin_dbeta", ctypes.c_void_p),
         ("fin_count", ctypes.c_double), ("fin_momentum", ctypes.c_float), ("fin_eps", ctypes.c_float), ("fin_train", ctypes.c_int32),

@@ -390,6 +390,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
             unsigned pixs[G];
             u32x4_t l_res[G], l_acc[G], l_y[G], l_z[G];
             unsigned l_m[G], l_rm[G];
+            u32x4_t l_ry[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 live[g] = pix < P && ccol < p.Cout_store && !(dbg & 128);
@@ -409,6 +410,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                         if (pk.res_mask) l_rm[g] = pk.res_mask[(long)pix * mrow + ccol / EV];
                     }
                     if (p.accumulate) l_acc[g] = *reinterpret_cast<const u32x4_t*>(Y + yo[g]);
+                    if (p.relu_y) l_ry[g] = *reinterpret_cast<const u32x4_t*>((const OT*)p.relu_y + yo[g]);
                     if (bnb) {
                         l_y[g] = *reinterpret_cast<const u32x4_t*>(Ybn + yo[g]);
                         if (Zbn) l_z[g] = *reinterpret_cast<const u32x4_t*>(Zbn + yo[g]);
@@ -444,6 +446,20 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                         for (int e = 0; e < EV; ++e) a.v[e] = fmaxf(a.v[e], 0.f);
                     }
                     a.store(reinterpret_cast<OT*>(&v));
+                }
+                if (GENERAL && p.relu_y) {
+                    // ReLU backward: zero where the forward output t <= 0.  A positive float (16- or 32-bit) is a positive signed integer.
+                    if (OSZ == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned t = l_ry[g][e];
+                            const unsigned m = (((short)(t & 0xffffu)) > 0 ? 0xffffu : 0u) | (((short)(t >> 16)) > 0 ? 0xffff0000u : 0u);
+                            v[e] &= m;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ((int)l_ry[g][e] > 0) ? v[e] : 0u;
+                    }
                 }
                 if (GENERAL && pk.y2 && ccol >= pk.y2_c0)       // split output: channels >= y2_c0 live in their own dense tensor
                     *reinterpret_cast<u32x4_t*>((OT*)pk.y2 + (long)pixs[g] * pk.y2_sP + (ccol - pk.y2_c0)) = v;
@@ -554,7 +570,7 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_kernel(const
         for (int k = 1; k < MPN_MAX_SEG; ++k) l += (k < pk.nseg && tp >= pk.seg_tile0[k]) ? 1 : 0;
         l = __builtin_amdgcn_readfirstlane(l);                  // block-uniform: keep the level's geometry in scalar registers
         tp -= pk.seg_tile0[l];
-        p.x = pk.seg_x[l]; p.y = pk.seg_y[l];
+        p.x = pk.seg_x[l]; p.y = pk.seg_y[l]; p.relu_y = pk.seg_ry[l];
         p.H = p.Ho = pk.seg_H[l]; p.W = p.Wo = pk.seg_W[l];
         p.x_sH = (int64_t)p.W * pk.x_sW; p.x_sB = (int64_t)p.H * p.x_sH;
         p.y_sB = (int64_t)p.H * p.W * pk.y_sP;
@@ -713,7 +729,7 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
         for (int k = 1; k < MPN_MAX_SEG; ++k) l += (k < pk.nseg && tp >= pk.seg_tile0[k]) ? 1 : 0;
         l = __builtin_amdgcn_readfirstlane(l);
         tp -= pk.seg_tile0[l];
-        p.x = pk.seg_x[l]; p.y = pk.seg_y[l];
+        p.x = pk.seg_x[l]; p.y = pk.seg_y[l]; p.relu_y = pk.seg_ry[l];
         p.H = p.Ho = pk.seg_H[l]; p.W = p.Wo = pk.seg_W[l];
         p.x_sH = (int64_t)p.W * pk.x_sW; p.x_sB = (int64_t)p.H * p.x_sH;
         p.y_sB = (int64_t)p.H * p.W * pk.y_sP;
@@ -942,7 +958,8 @@ int launch_conv(const MpnConvParams& p, hipStream_t st) {
     if (grid <= 0 || grid > 0x7fffffffL || P >= 0x7fffffffL) return MPN_E_BADARG;
     static const int dbg = getenv("MPN_DEBUG_FLAGS") ? atoi(getenv("MPN_DEBUG_FLAGS")) : 0;   // microbenchmark ablations only
     // "plain" = conv (+ BN tile statistics): no per-element epilogue math at all, lighter register footprint
-    const bool general = p.scale || p.bias || p.res_mode || p.accumulate || p.act || (p.Cout % tc) != 0 || p.bnb_partial || p.y2;
+    const bool general = p.scale || p.bias || p.res_mode || p.accumulate || p.act || (p.Cout % tc) != 0 || p.bnb_partial || p.y2 ||
+                         p.relu_y || (p.nseg > 0 && p.seg_ry[0]);
     return general ? launch_conv_k<T, OUTF32, true>(p, tc, grid, dbg, st) : launch_conv_k<T, OUTF32, false>(p, tc, grid, dbg, st);
 }
 
@@ -990,6 +1007,8 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
             if ((int64_t)p.B * (p.H >> p.kseg_shift[k]) * (p.W >> p.kseg_shift[k]) * p.kseg_c * 2 >= 0x7ffffff0LL) return MPN_E_UNSUPPORTED;
         }
     }
+    MPN_CHECK_ARG(!(p.relu_y || (p.nseg > 0 && p.seg_ry[0])) || (!p.out_f32 && !p.stats && !p.bnb_partial && !p.y2 && !p.act));
+    for (int l = 1; l < p.nseg; ++l) MPN_CHECK_ARG((p.seg_ry[l] != nullptr) == (p.seg_ry[0] != nullptr));
     MPN_CHECK_ARG(!p.y2 || (p.y2_c0 > 0 && p.y2_c0 % 8 == 0 && p.y2_c0 < p.Cout_store && p.y2_sP >= p.Cout_store - p.y2_c0 && !p.res_mode &&
                             !p.accumulate && !p.stats && !p.bnb_partial && !p.nseg && !p.out_f32));
     MPN_CHECK_ARG(p.w && p.B > 0);

@@ -85,7 +85,7 @@ class Act(object):
 
     Cs (channel storage) is a multiple of 32; lanes [C, Cs) hold zeros (see include/mpn.h).
     """
-    __slots__ = ("t", "B", "H", "W", "C", "Cs", "needs_grad", "tag", "seg", "cons", "bn_src", "mask", "conv_cons")
+    __slots__ = ("t", "B", "H", "W", "C", "Cs", "needs_grad", "tag", "seg", "cons", "bn_src", "mask", "conv_cons", "relu_out", "premasked", "other_cons")
 
     def __init__(self, t, C, needs_grad=False, tag=""):
         self.t = t
@@ -96,6 +96,9 @@ class Act(object):
         self.seg = None          # (flat buffer, index) when this activation is one level of a pyramid group (alloc_seg)
         self.cons = 0            # gradient contributions still to come in backward (engine: last-contributor detection)
         self.bn_src = None       # (y, BNState, relu, has_residual) when this is the output of a BatchNorm
+        self.relu_out = False    # forward: this tensor is relu(conv(.)) (conv epilogue act 1)
+        self.premasked = False   # gradient tensors: already multiplied by the ReLU mask of the tensor they belong to (dgrad epilogue)
+        self.other_cons = 0      # consumers other than plain / pyramid convolutions (residual adds, relu, pooling)
         self.conv_cons = 0       # how many of the pending contributions are input gradients of plain convolutions (engine.conv)
         self.mask = None         # sign bits of this tensor (uint8 [P, Cs / V]) when bn_act produced them for the backward pass
 
@@ -209,7 +212,7 @@ def seg_flat(acts):
     return flat if sum(a.t.numel() for a in acts) == flat.numel() else None
 
 
-def conv_forward_seg(xs, w, Cout, R, S, pad, bias=None, act=0, out_f32=False, mode=0, outs=None, accumulate=False, cin=None):
+def conv_forward_seg(xs, w, Cout, R, S, pad, bias=None, act=0, out_f32=False, mode=0, outs=None, accumulate=False, cin=None, relu_ys=None):
     """The same convolution (stride 1, same-size output) over every level of a pyramid in ONE launch — the shared RetinaNet
     towers of posenet.py:327-328.  xs: Acts with equal B / C / dtype.  Returns the per-level outputs (views of one buffer)."""
     x0 = xs[0]
@@ -233,6 +236,9 @@ def conv_forward_seg(xs, w, Cout, R, S, pad, bias=None, act=0, out_f32=False, mo
     for l, (x, o) in enumerate(zip(xs, outs)):
         assert (x.B, x.Cs, x.t.dtype) == (x0.B, x0.Cs, dt) and (o.H, o.W, o.Cs, o.t.dtype) == (x.H, x.W, outs[0].Cs, odt)
         p.seg_x[l], p.seg_y[l] = x.t.data_ptr(), o.t.data_ptr()
+        if relu_ys is not None:            # ReLU-backward mask of the tensor whose gradient this launch writes (MpnConvParams.seg_ry)
+            assert relu_ys[l].t.shape == o.t.shape and relu_ys[l].t.dtype == o.t.dtype
+            p.seg_ry[l] = relu_ys[l].t.data_ptr()
         p.seg_H[l], p.seg_W[l] = x.H, x.W
         p.seg_tile0[l] = tile0
         tile0 += (x.B * x.H * x.W + 127) // 128
@@ -241,7 +247,7 @@ def conv_forward_seg(xs, w, Cout, R, S, pad, bias=None, act=0, out_f32=False, mo
         e0 = KERNEL_EVENTS.begin()
         call("mpn_conv_forward", ctypes.byref(p), stream_ptr())
         tc = call("mpn_conv_tile_rows", ctypes.byref(p))
-        general = (bias is not None or accumulate or act != 0 or Cout % tc != 0)
+        general = (bias is not None or accumulate or act != 0 or Cout % tc != 0 or relu_ys is not None)
         name = ("conv_igemm_s3_kernel" if call("mpn_conv_shared_tile", ctypes.byref(p)) == 1 else "conv_igemm_kernel") + "<%s, %d, 128, %s, %s>" % (dtype_name(dt), tc, "true" if p.out_f32 else "false", "true" if general else "false")
         if KERNEL_EVENTS.detail:
             name = "%s %dx%d %d->%d pyramid(%s)|0" % ("dgrad" if mode == 1 else "fwd", R, S, p.Cin, Cout, ",".join(str(x.H) for x in xs))
@@ -396,7 +402,7 @@ def conv_out_hw(H, W, R, S, stride, pad):
 def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, res=None, res_mode=0,
                  want_stats=False, out_f32=False, out=None, accumulate=False, mode=0, out_hw=None,
                  cin=None, x_geom=None, y_geom=None, cout_store=None, needs_grad=False, tag="", bnb=None, bn_fin=None, res_mask=None,
-                 split=None):
+                 split=None, relu_y=None):
     """Implicit-GEMM convolution.  x: Act.  w: compute-dtype tensor laid out [Cout][R][S][Cin].
 
     mode 0 = forward gather, mode 1 = dgrad gather (then ``out_hw`` is the input-gradient size and
@@ -429,6 +435,9 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         p.y = yt.data_ptr()
         p.y_sB, p.y_sP = ysB, ysP
         p.Cout_store = cout_store if cout_store is not None else round_up(Cout, 4)
+    if relu_y is not None:                # ReLU-backward mask in the epilogue (MpnConvParams.relu_y)
+        assert relu_y.t.shape == out.t.shape and relu_y.t.dtype == out.t.dtype
+        p.relu_y = relu_y.t.data_ptr()
     if split is not None:
         # split=(y2 Act, c0): output channels >= c0 are written to y2 (dense, y2.Cs channels), the rest to `out` (row stride out.Cs):
         # the launch computes c0 + y2.C channels in all
@@ -508,7 +517,8 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         live = (R * S) / float(stride * stride) if mode == 1 else R * S
         flops = 2.0 * x.B * Ho * Wo * Cout * live * min(Cin, x.C if x_geom is None else Cin)
         # the name rocprofv3 prints for this instantiation (tools/rocprof_summary.py spelling)
-        general = (scale is not None or bias is not None or res is not None or accumulate or act != 0 or Cout % tc != 0 or bnb is not None)
+        general = (scale is not None or bias is not None or res is not None or accumulate or act != 0 or Cout % tc != 0 or bnb is not None
+                   or relu_y is not None or split is not None)
         kind = call("mpn_conv_shared_tile", ctypes.byref(p))
         name = ("conv_igemm_s3_kernel" if kind == 1 else "conv_igemm_kernel") + "<%s, %d, 128, %s, %s>" % (dtype_name(dt), tc,
                                                           "true" if p.out_f32 else "false", "true" if general else "false")

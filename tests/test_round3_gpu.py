@@ -499,3 +499,44 @@ def test_virtual_concat_equals_the_materialised_concatenation(dtype):
     assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), "virtual concatenation changed the training step"
     report("virtual concatenation (conv2 of the keypoint head): forward / weight gradient / input gradient bit-identical to the "
            "materialised 512-channel tensor; whole keypoint step bit-identical")
+
+
+# ------------------------------------------------------------------------------------------------ ReLU backward in the dgrad epilogue
+@pytest.mark.parametrize("dtype,pyramid", [(torch.bfloat16, True), (torch.float32, True), (torch.bfloat16, False)])
+def test_relu_backward_in_the_producing_dgrad_epilogue(dtype, pyramid):
+    """relu(conv(.)) layers (the RetinaNet towers posenet.py:48-66,91-109 and conv2 :313): the gradient that reaches such a layer
+    is masked by the input-gradient launch that produces it (MpnConvParams.relu_y / seg_ry) instead of a separate relu_backward
+    pass.  Same predicate on the same values: loss and every gradient of a `train_both` step bit-identical with the fusion on and
+    off, for the one-launch-per-pyramid towers and for the per-level launches."""
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    from oracle import weightgen
+    m = get_model(50, dtype)
+    for p in m.prn.parameters():
+        p.requires_grad = False
+    m.train()
+    Bn, S = 2, 128
+    img = t(weightgen.gen_images(820, Bn, S, S)).cuda()
+    heat, wgt = (t(a).cuda() for a in weightgen.gen_keypoint_gt(821, Bn, S // 4, S // 4))
+    anno = t(weightgen.gen_boxes_gt(822, Bn, S)).cuda()
+    bn_state = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
+    eng = m._engine
+    old = (eng.fuse_relu_bwd, eng.pyramid_towers)
+    outs = []
+    try:
+        eng.pyramid_towers = pyramid
+        for on in (False, True):
+            eng.fuse_relu_bwd = on
+            m.load_state_dict(bn_state, strict=False)
+            m._arena.ensure_grads()
+            m._arena.grad_flat.zero_()
+            pred, saved = m([img, "train_both"])
+            loss, _ = poseNet.build_loss(saved, "train_both", heat, wgt, anno)
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append((loss.detach().clone(), m._arena.grad_flat.clone()))
+    finally:
+        eng.fuse_relu_bwd, eng.pyramid_towers = old
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "fused ReLU backward changed the gradients"
+    w = m.regressionModel.conv2.weight
+    assert float(w.grad.abs().max()) > 0
+    report("ReLU backward fused into the producing dgrad (%s, %s towers): train_both step bit-identical" % (str(dtype), "pyramid" if pyramid else "per-level"))
