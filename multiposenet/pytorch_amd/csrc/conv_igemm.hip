@@ -224,7 +224,12 @@ __device__ __forceinline__ void fin_last_arriver(const MpnConvParams& p, int c0,
 // conv+BN-stats case.  BN partial sums use DPP row reductions.  Phase B: the finished tile goes through a
 // per-wave LDS staging area and leaves as 16-byte stores with 8..16 lanes covering one pixel's contiguous
 // channels (full 128-byte lines per wave-instruction).
-template <typename T, typename OT, int TC, int TP, bool GENERAL>
+// EXT (general kernels only) compiles in the rarely used epilogue features — both a residual AND accumulate, BatchNorm-backward
+// statistics with the mask read from the z tensor, the ReLU-backward mask (relu_y), the split output (y2).  The standard general
+// instantiation serves everything the training / inference steps launch by default with ONE added tensor (residual, optionally
+// through mask bits, OR the previous output) and mask bits / recomputation for the statistics: with all features compiled into
+// one kernel the 128-row tile needed 80 - 97 spilled registers at its three-waves-per-SIMD budget (+3.3 ms/step, r03 trace).
+template <typename T, typename OT, int TC, int TP, bool GENERAL, bool EXT>
 __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&acc)[ConvCfg<T, TC, TP>::MC][ConvCfg<T, TC, TP>::MP],
                                               int c0, long p0, int wc, int wp, int lane, int tp, unsigned char* lds, const int dbg,
                                               int tc, int ntiles, const MpnConvParams& pk) {
@@ -345,7 +350,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
     const bool bnb = GENERAL && pk.bnb_partial != nullptr;
     const OT* __restrict__ Ybn = (const OT*)pk.bnb_y;
     const unsigned char* __restrict__ Mbn = pk.bnb_mask;         // sign bits of z (one byte per 16-byte chunk) instead of z itself
-    const OT* __restrict__ Zbn = Mbn ? nullptr : (const OT*)pk.bnb_z;
+    const OT* __restrict__ Zbn = (EXT && !Mbn) ? (const OT*)pk.bnb_z : nullptr;
     const int mrow = p.Cout_store / EV;                           // mask bytes per pixel
     float bs1[EV], bs2[EV], bmu[EV], bis[EV], bsc[EV], bsf[EV];
     if (bnb) {
@@ -386,16 +391,18 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
 #pragma unroll
         for (int k0 = 0; k0 < NIT; k0 += G) {
             bool live[G];
-            long yo[G];
-            unsigned pixs[G];
-            u32x4_t l_res[G], l_acc[G], l_y[G], l_z[G];
-            unsigned l_m[G], l_rm[G];
-            u32x4_t l_ry[G];
+            unsigned yo[G];                                     // element offsets (launcher: output-shaped tensors < 2^31 elements)
+            constexpr int GX = EXT ? G : 1;                      // arrays of the extended features (dead when !EXT)
+            unsigned pixs[GX];
+            u32x4_t l_add[G], l_y[G];                            // the added tensor (residual, or the previous output) / bnb_y
+            unsigned l_m[G], l_rm[G];                            // mask bytes: bnb_mask / res_mask
+            u32x4_t l_acc[GX], l_z[GX], l_ry[GX];
+            const bool add_acc = !EXT && p.res_mode == 0 && p.accumulate;      // standard kernel: accumulate rides in l_add
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 live[g] = pix < P && ccol < p.Cout_store && !(dbg & 128);
-                pixs[g] = pix;
-                yo[g] = (long)b * p.y_sB + (long)rem * p.y_sP + ccol;
+                if (EXT) pixs[g] = pix;
+                yo[g] = b * (unsigned)p.y_sB + rem * (unsigned)p.y_sP + (unsigned)ccol;
                 if (GENERAL && live[g]) {
                     if (p.res_mode != 0) {
                         long ro;
@@ -406,15 +413,16 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                             const unsigned rh = (ho * (unsigned)p.res_H) / (unsigned)p.Ho, rw = (wo * (unsigned)p.res_W) / (unsigned)p.Wo;
                             ro = (long)b * p.res_sB + (long)(rh * (unsigned)p.res_W + rw) * p.res_sP;
                         }
-                        l_res[g] = *reinterpret_cast<const u32x4_t*>(Rz + ro + ccol);
-                        if (pk.res_mask) l_rm[g] = pk.res_mask[(long)pix * mrow + ccol / EV];
+                        l_add[g] = *reinterpret_cast<const u32x4_t*>(Rz + ro + ccol);
+                        if (pk.res_mask) l_rm[g] = pk.res_mask[pix * (unsigned)mrow + (unsigned)(ccol / EV)];
                     }
-                    if (p.accumulate) l_acc[g] = *reinterpret_cast<const u32x4_t*>(Y + yo[g]);
-                    if (p.relu_y) l_ry[g] = *reinterpret_cast<const u32x4_t*>((const OT*)p.relu_y + yo[g]);
+                    if (add_acc) l_add[g] = *reinterpret_cast<const u32x4_t*>(Y + yo[g]);
+                    if (EXT && p.accumulate) l_acc[g] = *reinterpret_cast<const u32x4_t*>(Y + yo[g]);
+                    if (EXT && p.relu_y) l_ry[g] = *reinterpret_cast<const u32x4_t*>((const OT*)p.relu_y + yo[g]);
                     if (bnb) {
                         l_y[g] = *reinterpret_cast<const u32x4_t*>(Ybn + yo[g]);
-                        if (Zbn) l_z[g] = *reinterpret_cast<const u32x4_t*>(Zbn + yo[g]);
-                        if (Mbn) l_m[g] = Mbn[(long)pix * mrow + ccol / EV];
+                        if (EXT && Zbn) l_z[g] = *reinterpret_cast<const u32x4_t*>(Zbn + yo[g]);
+                        if (Mbn) l_m[g] = Mbn[pix * (unsigned)mrow + (unsigned)(ccol / EV)];
                     }
                 }
                 pix += PPI; rem += PPI;
@@ -427,16 +435,16 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                 if (GENERAL && (p.res_mode != 0 || p.accumulate)) {
                     // residual (same-size or nearest-upsampled source) and accumulate: 16-byte coalesced loads
                     Vec16<OT> a; a.load(reinterpret_cast<const OT*>(&v));
-                    if (p.res_mode != 0) {
-                        Vec16<OT> r; r.load(reinterpret_cast<const OT*>(&l_res[g]));
-                        if (pk.res_mask) {
+                    if (p.res_mode != 0 || add_acc) {
+                        Vec16<OT> r; r.load(reinterpret_cast<const OT*>(&l_add[g]));
+                        if (p.res_mode != 0 && pk.res_mask) {
 #pragma unroll
                             for (int e = 0; e < EV; ++e) r.v[e] = ((l_rm[g] >> e) & 1u) ? r.v[e] : 0.f;
                         }
 #pragma unroll
                         for (int e = 0; e < EV; ++e) a.v[e] += r.v[e];
                     }
-                    if (p.accumulate) {
+                    if (EXT && p.accumulate) {
                         Vec16<OT> r; r.load(reinterpret_cast<const OT*>(&l_acc[g]));
 #pragma unroll
                         for (int e = 0; e < EV; ++e) a.v[e] += r.v[e];
@@ -447,7 +455,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                     }
                     a.store(reinterpret_cast<OT*>(&v));
                 }
-                if (GENERAL && p.relu_y) {
+                if (EXT && p.relu_y) {
                     // ReLU backward: zero where the forward output t <= 0.  A positive float (16- or 32-bit) is a positive signed integer.
                     if (OSZ == 2) {
 #pragma unroll
@@ -461,7 +469,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                         for (int e = 0; e < 4; ++e) v[e] = ((int)l_ry[g][e] > 0) ? v[e] : 0u;
                     }
                 }
-                if (GENERAL && pk.y2 && ccol >= pk.y2_c0)       // split output: channels >= y2_c0 live in their own dense tensor
+                if (EXT && pk.y2 && ccol >= pk.y2_c0)           // split output: channels >= y2_c0 live in their own dense tensor
                     *reinterpret_cast<u32x4_t*>((OT*)pk.y2 + (long)pixs[g] * pk.y2_sP + (ccol - pk.y2_c0)) = v;
                 else
                     *reinterpret_cast<u32x4_t*>(Y + yo[g]) = v;
@@ -469,12 +477,12 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                     Vec16<OT> dzv, yy, zz;
                     dzv.load(reinterpret_cast<const OT*>(&v));                  // the value as stored
                     yy.load(reinterpret_cast<const OT*>(&l_y[g]));
-                    if (Zbn) zz.load(reinterpret_cast<const OT*>(&l_z[g]));
+                    if (EXT && Zbn) zz.load(reinterpret_cast<const OT*>(&l_z[g]));
 #pragma unroll
                     for (int e = 0; e < EV; ++e) {
                         float gg = dzv.v[e];
                         if (pk.bnb_relu) {
-                            const float zv = Mbn ? (((l_m[g] >> e) & 1u) ? 1.f : 0.f) : (Zbn ? zz.v[e] : yy.v[e] * bsc[e] + bsf[e]);
+                            const float zv = Mbn ? (((l_m[g] >> e) & 1u) ? 1.f : 0.f) : ((EXT && Zbn) ? zz.v[e] : yy.v[e] * bsc[e] + bsf[e]);
                             if (!(zv > 0.f)) gg = 0.f;
                         }
                         bs1[e] += gg;
@@ -552,7 +560,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // Halo pixels, rows past Cout / past the last pixel carry an out-of-range offset and arrive as zeros.  The loads
 // are invisible to the compiler's waitcnt pass: completion is counted by hand (vmcnt(LPS) = everything but the
 // newest k-step has landed) and the barrier is the raw s_barrier, so the ring never drains inside the loop.
-template <typename T, int TC, int TP, bool OUTF32, bool GENERAL>
+template <typename T, int TC, int TP, bool OUTF32, bool GENERAL, bool EXT = false>
 __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_kernel(const MpnConvParams pk, const int dbg) {
     using C = ConvCfg<T, TC, TP>;
     __shared__ __attribute__((aligned(16))) unsigned char lds[C::NST * C::STAGE_BYTES];
@@ -695,8 +703,8 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_kernel(const
 
     if (dbg & 16) { if (acc[0][0][0] == 123.456f) ((float*)p.y)[0] = 1.f; return; }   // ablation: no epilogue
     const int ntiles = (int)(gridDim.x / (unsigned)tilesC);       // pixel tiles of the launch (in-launch finalize)
-    if (OUTF32) conv_epilogue<T, float, TC, TP, GENERAL>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
-    else        conv_epilogue<T, T, TC, TP, GENERAL>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
+    if (OUTF32) conv_epilogue<T, float, TC, TP, GENERAL, EXT>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
+    else        conv_epilogue<T, T, TC, TP, GENERAL, EXT>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
 }
 
 // 3x3 / stride 1 / pad 1 variant (forward and stride-1 dgrad), 16-bit types: the k-loop is bound by operand delivery (global -> LDS
@@ -707,7 +715,7 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_kernel(const
 // taps; the vertical border is a property of the row itself (every consumer of a row sits in the same output line) and stays a
 // DMA-time zero fill.  Per group: 3 weight tiles + 1 pixel tile instead of 3 + 3 (-31 % DMA bytes, -25 % DMA instructions).
 // k order: (r, channel chunk, s).  LDS: weight ring 3 x A_BYTES, pixel ring 2 x 12 KB (same total as the generic kernel).
-template <typename T, int TC, int TP, bool OUTF32, bool GENERAL>
+template <typename T, int TC, int TP, bool OUTF32, bool GENERAL, bool EXT = false>
 __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(const MpnConvParams pk, const int dbg) {
     using C = ConvCfg<T, TC, TP>;
     static_assert(sizeof(T) == 2 && TP == 128, "16-bit operands, 128-pixel tiles");
@@ -759,9 +767,9 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
     }
     // pixel-tile DMA units: LDS row i holds input pixel (linear index) p0 - 1 + i of the line the current kernel row selects
     unsigned b_base[LB];
-    int b_h[LB], b_w[LB], b_bi[LB];
+    int b_h[LB], b_w[EXT ? LB : 1], b_bi[EXT ? LB : 1];           // (column, image) only for the virtual concatenation (EXT instantiation)
     bool b_ok[LB];
-    const bool vcat = pk.kseg_n > 0;                              // virtual channel concatenation of up-sampled sources (mpn.h: kseg_*)
+    const bool vcat = EXT && pk.kseg_n > 0;                       // virtual channel concatenation of up-sampled sources (mpn.h: kseg_*)
 #pragma unroll
     for (int q = 0; q < LB; ++q) {
         const int i = ((int)wave_u * LB + q) * 16 + u_row;
@@ -771,8 +779,10 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
         const unsigned bi = pcu / HoWo;
         const unsigned rem = pcu - bi * HoWo;
         b_h[q] = (int)(rem / (unsigned)p.Wo);
-        b_w[q] = (int)(rem - (unsigned)b_h[q] * (unsigned)p.Wo);
-        b_bi[q] = (int)bi;
+        if (EXT) {
+            b_w[q] = (int)(rem - (unsigned)b_h[q] * (unsigned)p.Wo);
+            b_bi[q] = (int)bi;
+        }
         b_ok[q] = ok;
         b_base[q] = (unsigned)(((long)pcu * p.x_sW + u_piece * C::V) * TS);
     }
@@ -819,22 +829,27 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
     auto issue_b = [&](unsigned slot) {
         const int dy = (p.mode == 0) ? br - 1 : 1 - br;           // input line relative to the output line
         const unsigned st = lds_base + A_RING + slot * B_BYTES;
-        if (vcat) {
-            // channel chunk bcc lives in segment sg = bcc / kseg_c: a dense [B][H >> sh][W >> sh][kseg_c] tensor read at (h >> sh, w >> sh)
-            const int sg = __builtin_amdgcn_readfirstlane(bcc / pk.kseg_c);
-            const int sh = __builtin_amdgcn_readfirstlane(pk.kseg_shift[sg]);
-            const int Hs = p.H >> sh, Ws = p.W >> sh;
-            const i32x4_t rs = make_rsrc(pk.kseg_x[sg], (unsigned)((long)p.B * Hs * Ws * pk.kseg_c * TS));
-            const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(bcc - sg * pk.kseg_c) * TS));
+        bool done = false;
+        if constexpr (EXT) {
+            if (vcat) {
+                // channel chunk bcc lives in segment sg = bcc / kseg_c: a dense [B][H >> sh][W >> sh][kseg_c] tensor read at (h >> sh, w >> sh)
+                const int sg = __builtin_amdgcn_readfirstlane(bcc / pk.kseg_c);
+                const int sh = __builtin_amdgcn_readfirstlane(pk.kseg_shift[sg]);
+                const int Hs = p.H >> sh, Ws = p.W >> sh;
+                const i32x4_t rs = make_rsrc(pk.kseg_x[sg], (unsigned)((long)p.B * Hs * Ws * pk.kseg_c * TS));
+                const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(bcc - sg * pk.kseg_c) * TS));
 #pragma unroll
-            for (int q = 0; q < LB; ++q) {
-                const int hh = b_h[q] + dy;
-                const bool ok = b_ok[q] && (unsigned)hh < (unsigned)p.H;
-                const unsigned src = (unsigned)((b_bi[q] * Hs + (hh >> sh)) * Ws + (b_w[q] >> sh));
-                const unsigned voff = ok ? (src * (unsigned)pk.kseg_c + (unsigned)(u_piece * C::V)) * TS : 0x80000000u;
-                lds_dma16(voff, rs, so, __builtin_amdgcn_readfirstlane(st + (wave_u * LB + q) * 1024u));
+                for (int q = 0; q < LB; ++q) {
+                    const int hh = b_h[q] + dy;
+                    const bool ok = b_ok[q] && (unsigned)hh < (unsigned)p.H;
+                    const unsigned src = (unsigned)((b_bi[q] * Hs + (hh >> sh)) * Ws + (b_w[q] >> sh));
+                    const unsigned voff = ok ? (src * (unsigned)pk.kseg_c + (unsigned)(u_piece * C::V)) * TS : 0x80000000u;
+                    lds_dma16(voff, rs, so, __builtin_amdgcn_readfirstlane(st + (wave_u * LB + q) * 1024u));
+                }
+                done = true;
             }
-        } else {
+        }
+        if (!done) {
             const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)bcc * TS));
 #pragma unroll
             for (int q = 0; q < LB; ++q) {
@@ -902,8 +917,8 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
     __syncthreads();
 
     const int ntiles = (int)(gridDim.x / (unsigned)tilesC);
-    if (OUTF32) conv_epilogue<T, float, TC, TP, GENERAL>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
-    else        conv_epilogue<T, T, TC, TP, GENERAL>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
+    if (OUTF32) conv_epilogue<T, float, TC, TP, GENERAL, EXT>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
+    else        conv_epilogue<T, T, TC, TP, GENERAL, EXT>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
 }
 
 constexpr int kTP = 128;
@@ -931,21 +946,27 @@ inline bool conv_uses_s3(const MpnConvParams& p, int tc) {
     return p.H == p.Ho && p.W == p.Wo && p.x_sH == (int64_t)p.W * p.x_sW && p.x_sB == (int64_t)p.H * p.x_sH;
 }
 
-template <typename T, bool OUTF32, bool GENERAL>
+template <typename T, bool OUTF32, bool GENERAL, bool EXT = false>
 int launch_conv_k(const MpnConvParams& p, int tc, long grid, int dbg, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         if (conv_uses_s3(p, tc)) {
-            if (tc == 256) hipLaunchKernelGGL((conv_igemm_s3_kernel<T, 256, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
-            else if (tc == 128) hipLaunchKernelGGL((conv_igemm_s3_kernel<T, 128, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
-            else hipLaunchKernelGGL((conv_igemm_s3_kernel<T, 64, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+            if (tc == 256) hipLaunchKernelGGL((conv_igemm_s3_kernel<T, 256, kTP, OUTF32, GENERAL, EXT>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+            else if (tc == 128) hipLaunchKernelGGL((conv_igemm_s3_kernel<T, 128, kTP, OUTF32, GENERAL, EXT>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+            else hipLaunchKernelGGL((conv_igemm_s3_kernel<T, 64, kTP, OUTF32, GENERAL, EXT>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
             return mpn_launch_status();
         }
     }
-    if (tc == 256) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
-    else if (tc == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
-    else if (tc == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
-    else hipLaunchKernelGGL((conv_igemm_kernel<T, 32, kTP, OUTF32, GENERAL>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+    if (tc == 256) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, kTP, OUTF32, GENERAL, EXT>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+    else if (tc == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, kTP, OUTF32, GENERAL, EXT>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+    else if (tc == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, kTP, OUTF32, GENERAL, EXT>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+    else hipLaunchKernelGGL((conv_igemm_kernel<T, 32, kTP, OUTF32, GENERAL, EXT>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
     return mpn_launch_status();
+}
+
+// the extended epilogue (see conv_epilogue): only when a launch asks for one of its features
+inline bool conv_needs_ext(const MpnConvParams& p) {
+    return p.relu_y || (p.nseg > 0 && p.seg_ry[0]) || p.y2 || (p.bnb_partial && p.bnb_relu && p.bnb_z && !p.bnb_mask) ||
+           (p.res_mode && p.accumulate) || p.kseg_n > 0;
 }
 
 template <typename T, bool OUTF32>
@@ -960,6 +981,10 @@ int launch_conv(const MpnConvParams& p, hipStream_t st) {
     // "plain" = conv (+ BN tile statistics): no per-element epilogue math at all, lighter register footprint
     const bool general = p.scale || p.bias || p.res_mode || p.accumulate || p.act || (p.Cout % tc) != 0 || p.bnb_partial || p.y2 ||
                          p.relu_y || (p.nseg > 0 && p.seg_ry[0]);
+    if (conv_needs_ext(p)) {
+        if constexpr (OUTF32) return MPN_E_UNSUPPORTED;          // none of the extended features writes f32 from 16-bit operands
+        else return launch_conv_k<T, false, true, true>(p, tc, grid, dbg, st);
+    }
     return general ? launch_conv_k<T, OUTF32, true>(p, tc, grid, dbg, st) : launch_conv_k<T, OUTF32, false>(p, tc, grid, dbg, st);
 }
 
@@ -1035,6 +1060,9 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
         int64_t xb = (int64_t)p.B * p.x_sB * ts;
         for (int l = 0; l < p.nseg; ++l) { const int64_t v = (int64_t)p.B * p.seg_H[l] * p.seg_W[l] * p.x_sW * ts; if (l == 0 || v > xb) xb = v; }
         if (xb + row >= 0xfffffff0LL || (int64_t)(p.Cout + 1) * row >= 0xfffffff0LL) return MPN_E_UNSUPPORTED;
+        int64_t ye = (int64_t)p.B * p.y_sB;                       // the epilogue indexes output-shaped tensors with 32-bit element offsets
+        for (int l = 0; l < p.nseg; ++l) { const int64_t v = (int64_t)p.B * p.seg_H[l] * p.seg_W[l] * p.y_sP; if (l == 0 || v > ye) ye = v; }
+        if (ye >= 0x7fffffffLL) return MPN_E_UNSUPPORTED;
     }          // activation is applied before the residual stage
     hipStream_t st = (hipStream_t)stream;
     if (mpn_conv_pw_selected(&p)) return mpn_conv_pw_forward(&p, stream);   // short-K wide-output 1x1: pixel tile resident in LDS (conv_pw.hip)

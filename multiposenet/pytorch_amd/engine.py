@@ -103,6 +103,7 @@ class Engine(object):
         # torch.cat((up8(q5), up4(q4), up2(q3), q2), 1) -> conv2 (posenet.py:311-315): the 512-channel tensor is never written; conv2's
         # forward and weight-gradient launches gather from the four members, its input gradient lands in q2's gradient directly
         self.virtual_concat = os.environ.get("MPN_VIRTUAL_CONCAT", "1") != "0"
+        self.cat_split_dgrad = os.environ.get("MPN_CAT_SPLIT_DGRAD", "0") != "0"
         # relu(conv(.)) layers (RetinaNet towers, conv2): the ReLU-backward mask can be applied by the input-gradient launch that
         # PRODUCES the gradient (MpnConvParams.relu_y) instead of a separate relu_backward pass over it.  Bit-identical, and measured
         # neutral (41.55 vs 41.67 ms in one call: the pass it removes costs what the extra epilogue load of eight MFMA-bound tower
@@ -660,7 +661,9 @@ class Engine(object):
         if any(s.needs_grad for s in srcs):
             wt = self.w_t(ctx, layer)
             last = srcs[-1]
-            direct = last.needs_grad and last.H == H and last.W == W and len(srcs) > 1
+            # split output (q2's gradient written by the dgrad launch itself): measured slower than the plain kernel plus a slice copy
+            # (1 121 vs 876 + ~50 us: the split needs the extended general epilogue) — off unless MPN_CAT_SPLIT_DGRAD=1
+            direct = self.cat_split_dgrad and last.needs_grad and last.H == H and last.W == W and len(srcs) > 1
             c0 = sum(s.Cs for s in (srcs[:-1] if direct else srcs))
             d_rest = Act(torch.empty((dy.B, H, W, c0), dtype=dy.t.dtype, device=dy.t.device), c0)
             g_last = Act(torch.empty_like(last.t), last.C) if direct else None
