@@ -450,6 +450,18 @@ int mpn_prn_build_maps(const double* peaks, const int32_t* joint_off, const doub
                        void* stream);
 int mpn_prn_scores(const float* prn_out, const int32_t* occ, int nboxes, int H, int W, int N, float* score, int32_t* argmax,
                    void* stream);
+/* mpn_prn_scores with a compact result (the full score / occupancy planes are 274 KB per box): per (box, joint type) the occupied
+ * cells in row-major order — np.argwhere's order at tester.py:415 — as cand_id (peak id = occ - 1) and cand_score (window sum),
+ * at most `cap` per plane (cand_n holds the true count; *overflow is set when one exceeds cap), plus the per-plane arg-max. */
+int mpn_prn_scores_compact(const float* prn_out, const int32_t* occ, int nboxes, int H, int W, int N, int cap,
+                           int32_t* cand_n, int32_t* cand_id, float* cand_score, int32_t* argmax, int32_t* overflow, void* stream);
+/* HOST function (no device work, host pointers): the greedy (boxes x peaks) matching of tester.py:432-485 for a whole batch on the
+ * compact candidate lists.  box_start [nimg+1]: the boxes of image i are box_start[i] .. box_start[i+1]; boxes (x, y, w, h);
+ * joint_off / peaks as for mpn_prn_build_maps; out_kp [nb][17][3] (x, y, score) must be zero-filled.  Where the result would depend
+ * on numpy's ordering of EQUAL positive scores, tie_flags[image*17 + type] is set and that pair is left to the caller. */
+int mpn_prn_match_host(int nimg, const int32_t* box_start, const double* boxes, const int32_t* joint_off, const double* peaks,
+                       const int32_t* cand_n, const int32_t* cand_id, const float* cand_score, int cap, const int32_t* argmax,
+                       int H, int W, double* out_kp, uint8_t* tie_flags);
 
 #ifdef __cplusplus
 }

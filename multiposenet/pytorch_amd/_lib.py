@@ -75,6 +75,8 @@ SIGNATURES = {
     "mpn_resize": (_i, [_vp, _i64, _i64, _i64, _i, _i, _i, _vp, _i, _i, _i, ctypes.c_double, ctypes.c_double, _vp]),
     "mpn_prn_build_maps": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, ctypes.c_double, _vp, _vp, _vp, _vp, _vp]),
     "mpn_prn_scores": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mpn_prn_scores_compact": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mpn_prn_match_host": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
     "mpn_conv_stats_tiles": (_i, [_PC]),
     "mpn_conv_pw_supported": (_i, [_PC]),
     "mpn_conv_pw_selected": (_i, [_PC]),

@@ -161,7 +161,170 @@ __global__ void __launch_bounds__(64) prn_scores_kernel(const float* __restrict_
     if (lane == 0) argmax[b * 17 + t] = best_i;
 }
 
+// prn_scores_kernel with a COMPACT result: instead of the full [nb][17][H][W] score plane (274 KB per box with its occupancy map:
+// 140 MB per 64-image batch over PCIe), the occupied cells of every (box, joint type) plane leave as a short list in row-major cell
+// order — exactly the order np.argwhere visits them at tester.py:415 — of (peak id, window score).
+__global__ void __launch_bounds__(64) prn_scores_compact_kernel(const float* __restrict__ prn_out, const int* __restrict__ occ,
+                                                                int H, int W, int N, int cap,
+                                                                int* __restrict__ cand_n,          // [nb][17]
+                                                                int* __restrict__ cand_id,         // [nb][17][cap] peak id (occ - 1)
+                                                                float* __restrict__ cand_score,    // [nb][17][cap]
+                                                                int* __restrict__ argmax, int* __restrict__ overflow) {
+    const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int n = H * W;
+    const float* plane = prn_out + (long)b * n * 17 + t;
+    const int* oc = occ + ((long)b * 17 + t) * n;
+    const long slot0 = ((long)b * 17 + t) * cap;
+    const int half = (N - 1) / 2;
+    float best = -INFINITY;
+    int best_i = 0x7fffffff;
+    int count = 0;                                                 // wave-uniform
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const bool in = i < n;
+        const float v = in ? plane[(long)i * 17] : -INFINITY;
+        if (in && v > best) { best = v; best_i = i; }
+        const int o = in ? oc[i] : 0;
+        const bool hit = o > 0;
+        const unsigned long long m = __ballot(hit);
+        if (hit) {
+            const int y = i / W, x = i - y * W;
+            const int r0 = y - half < 0 ? 0 : y - half, r1 = y + half + 1 > H - 1 ? H : y + half + 1;
+            const int c0 = x - half < 0 ? 0 : x - half, c1 = x + half + 1 > W - 1 ? W : x + half + 1;
+            WinView wv = {plane, W, r0, c0, c1 - c0};
+            const float sc = np_sum_window(wv, (r1 - r0) * (c1 - c0));
+            const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < cap) { cand_id[slot0 + pos] = o - 1; cand_score[slot0 + pos] = sc; }
+        }
+        count += __popcll(m);
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) {
+        const float ov = __shfl_xor(best, k, 64);
+        const int oi = __shfl_xor(best_i, k, 64);
+        if (ov > best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+    }
+    if (lane == 0) {
+        argmax[b * 17 + t] = best_i;
+        cand_n[b * 17 + t] = count;
+        if (count > cap) atomicExch(overflow, 1);
+    }
+}
+
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Host half of the assignment (tester.py:432-485) on the compact candidate lists: plain C++, no device work.  For every image and
+// joint type the (boxes x peaks) score table is matched greedily exactly as the reference's numpy loops do.  Where the outcome
+// would depend on how np.argsort orders EQUAL positive scores (numpy's small-array sorts are SIMD networks, not stable: the
+// order is an implementation detail of the numpy build) the function does not guess: it flags that (image, joint type) in
+// `tie_flags` and leaves it to the caller's numpy path.
+// ---------------------------------------------------------------------------------------------------------------------------
+extern "C" int mpn_prn_match_host(int nimg, const int32_t* box_start /*[nimg+1]*/, const double* boxes /*[nb][4] x,y,w,h*/,
+                                  const int32_t* joint_off /*[nimg][18]*/, const double* peaks /*[np][2]*/,
+                                  const int32_t* cand_n /*[nb][17]*/, const int32_t* cand_id, const float* cand_score, int cap,
+                                  const int32_t* argmax /*[nb][17]*/, int H, int W,
+                                  double* out_kp /*[nb][17][3], zero-filled by the caller*/, uint8_t* tie_flags /*[nimg][17]*/) {
+    if (!box_start || !boxes || !joint_off || !peaks || !cand_n || !cand_id || !cand_score || !argmax || !out_kp || !tie_flags) return MPN_E_BADARG;
+    for (int im = 0; im < nimg; ++im) {
+        const int b0 = box_start[im], n = box_start[im + 1] - b0;
+        if (n <= 0) continue;
+        const int first = joint_off[im * 18];
+        bool any_empty = false;
+        for (int t = 0; t < 17; ++t) {
+            // columns = distinct peak ids among the candidates of this joint type (a peak id names one peak of this image)
+            int ids[512];
+            int ncol = 0;
+            int total = 0;
+            for (int bi = 0; bi < n; ++bi) {
+                const int c = cand_n[(b0 + bi) * 17 + t];
+                total += c;
+                if (c > cap) { tie_flags[im * 17 + t] = 1; break; }    // list truncated on the device: the caller's full-table path
+                for (int k = 0; k < c && k < cap; ++k) {
+                    const int id = cand_id[((long)(b0 + bi) * 17 + t) * cap + k];
+                    int j = 0;
+                    while (j < ncol && ids[j] != id) ++j;
+                    if (j == ncol) { if (ncol >= 512) { tie_flags[im * 17 + t] = 1; break; } ids[ncol++] = id; }
+                }
+            }
+            if (total == 0) { any_empty = true; continue; }
+            if (tie_flags[im * 17 + t]) continue;
+            // table[bi][col]
+            double table[64 * 64];
+            if (n > 64 || ncol > 64) { tie_flags[im * 17 + t] = 1; continue; }
+            for (int k = 0; k < n * ncol; ++k) table[k] = 0.0;
+            for (int bi = 0; bi < n; ++bi) {
+                const int c = cand_n[(b0 + bi) * 17 + t];
+                for (int k = 0; k < c; ++k) {
+                    const long q = ((long)(b0 + bi) * 17 + t) * cap + k;
+                    int j = 0;
+                    while (ids[j] != cand_id[q]) ++j;
+                    table[bi * ncol + j] = (double)cand_score[q];
+                }
+            }
+            // any two equal positive entries in one row or one column could make the answer depend on argsort's tie order
+            bool tie = false;
+            for (int bi = 0; bi < n && !tie; ++bi)
+                for (int a = 0; a < ncol && !tie; ++a)
+                    for (int c2 = a + 1; c2 < ncol; ++c2)
+                        if (table[bi * ncol + a] > 0.0 && table[bi * ncol + a] == table[bi * ncol + c2]) { tie = true; break; }
+            for (int a = 0; a < ncol && !tie; ++a)
+                for (int bi = 0; bi < n && !tie; ++bi)
+                    for (int b2 = bi + 1; b2 < n; ++b2)
+                        if (table[bi * ncol + a] > 0.0 && table[bi * ncol + a] == table[b2 * ncol + a]) { tie = true; break; }
+            if (tie) { tie_flags[im * 17 + t] = 1; continue; }
+            for (int bi = 0; bi < n; ++bi) {                       // tester.py:453-470
+                bool used[64];
+                for (int a = 0; a < ncol; ++a) used[a] = false;
+                for (int step = 0; step < ncol; ++step) {          // columns of this row by descending score
+                    int r = -1;
+                    for (int a = 0; a < ncol; ++a)
+                        if (!used[a] && (r < 0 || table[bi * ncol + a] > table[bi * ncol + r])) r = a;
+                    used[r] = true;
+                    if (!(table[bi * ncol + r] > 0.0)) break;      // the rest of the row is empty
+                    int bestb = 0;                                  // the box that scores highest for this peak
+                    for (int b2 = 1; b2 < n; ++b2) if (table[b2 * ncol + r] > table[bestb * ncol + r]) bestb = b2;
+                    bool take = bestb == bi;
+                    if (!take) {                                    // ... or this peak is that box's WORST column (np.argsort(table[best])[0] == r):
+                        bool is_min = true;                         // impossible while that row holds an empty (zero) cell, since table[best][r] > 0
+                        for (int a = 0; a < ncol; ++a)
+                            if (a != r && table[bestb * ncol + a] <= table[bestb * ncol + r]) { is_min = false; break; }
+                        take = is_min;
+                    }
+                    if (take) {
+                        const int pid = first + ids[r];
+                        double* o = out_kp + ((long)(b0 + bi) * 17 + t) * 3;
+                        o[0] = peaks[(long)pid * 2]; o[1] = peaks[(long)pid * 2 + 1]; o[2] = 1.0;
+                        break;
+                    }
+                }
+            }
+        }
+        if (any_empty) {                                            // tester.py:471-483: joint types nobody has -> the PRN's arg-max cell
+            for (int bi = 0; bi < n; ++bi) {
+                const double* bx = boxes + (long)(b0 + bi) * 4;
+                const double x_scale = (double)W / ceil(bx[2]), y_scale = (double)H / ceil(bx[3]);
+                for (int t = 0; t < 17; ++t) {
+                    if (cand_n[(b0 + bi) * 17 + t] != 0) continue;
+                    const int am = argmax[(b0 + bi) * 17 + t];
+                    const int my = am / W, mx = am - my * W;
+                    double* o = out_kp + ((long)(b0 + bi) * 17 + t) * 3;
+                    o[0] = (double)mx / x_scale + bx[0]; o[1] = (double)my / y_scale + bx[1]; o[2] = 0.0;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+extern "C" int mpn_prn_scores_compact(const float* prn_out, const int32_t* occ, int nboxes, int H, int W, int N, int cap,
+                                      int32_t* cand_n, int32_t* cand_id, float* cand_score, int32_t* argmax, int32_t* overflow, void* stream) {
+    MPN_CHECK_ARG(prn_out && occ && cand_n && cand_id && cand_score && argmax && overflow && nboxes > 0 && H > 0 && W > 0 && cap > 0 &&
+                  N > 0 && N <= 15 && (N & 1));
+    hipLaunchKernelGGL(prn_scores_compact_kernel, dim3(17, nboxes), dim3(64), 0, (hipStream_t)stream, prn_out, occ, H, W, N, cap, cand_n,
+                       cand_id, cand_score, argmax, overflow);
+    return mpn_launch_status();
+}
 
 extern "C" int mpn_prn_build_maps(const double* peaks, const int32_t* joint_off, const double* boxes, const int32_t* box_img, int nboxes,
                                   int H, int W, double in_thres, const double* weights9, int32_t* occ, float* prn_in, int32_t* err,

@@ -7,10 +7,13 @@ the MI355X and ONE batched PRN forward for all boxes (of all images) instead of 
 ``kps`` rows are ``(x, y, score, id, joint_type 0..16)`` as produced at tester.py:158-166 from ``get_joint_list``;
 ``bbox_list`` rows are ``(x1, y1, x2, y2)``.  Device side (csrc/prn_assign.hip): the one-hot peak maps with the
 reference's cell arithmetic, the skimage-gaussian blur, the PRN (``model.prn_forward`` on the conv kernels), the 15x15
-window scores and the per-plane arg-max.  Host side (this file): the tiny greedy table matching of tester.py:432-470 on
-the (boxes x peaks) score table — integer/argsort logic over a few dozen numbers, kept in numpy so that ties resolve
-exactly as in the reference (``list(set(...))`` order, ``np.argsort``'s default sort).
+window scores — compacted on the device to per-plane candidate lists — and the per-plane arg-max.  Host side: the greedy table
+matching of tester.py:432-470 in C++ (``mpn_prn_match_host``) on those lists; wherever the result would depend on how numpy orders
+EQUAL scores (``np.argsort``'s tie order is a property of the numpy build: its small-array sorts are not stable) the full score
+tables come back and the reference's own numpy expressions decide (``_assign``).  ``prn_assign_arrays`` is the batched entry
+point on flat arrays; ``prn_process`` / ``prn_process_batch`` keep the reference's list / dict interface on top of it.
 """
+import ctypes
 import math
 
 import numpy as np
@@ -39,43 +42,41 @@ def _peaks_by_joint(kps):
     return peaks
 
 
-def prn_process_batch(model, kps_list, bbox_lists, file_names=None, image_ids=None, coeff=2, in_thres=0.21):
-    nimg = len(kps_list)
-    file_names = file_names if file_names is not None else [""] * nimg
-    image_ids = image_ids if image_ids is not None else [0] * nimg
-    w, h = int(18 * coeff), int(28 * coeff)
-    if (h, w) != (56, 36):
-        raise MpnError("the reference reshapes the PRN output to (56, 36, 17) (tester.py:404): coeff must be 2")
+CAND_CAP = 64          # candidates kept per (box, joint type) plane by the compact score kernel; more -> the full-table path
+
+
+def prn_assign_arrays(model, peaks_xy, joint_off, boxes_xywh, box_start, in_thres=0.21, fast=True):
+    """The assignment for a whole batch on flat arrays — the form the device kernels take and the form a batched caller has.
+
+    peaks_xy  float64 [Np, 2]   heat-map peaks (x, y), grouped by image, then by joint type 0..16, in detection order
+    joint_off int32  [nimg, 18] offsets of those groups into peaks_xy
+    boxes_xywh float64 [nb, 4]  detected boxes (x, y, w, h), grouped by image
+    box_start int32  [nimg + 1] boxes of image i = box_start[i] .. box_start[i + 1]
+    Returns keypoints float64 [nb, 17, 3] (x, y, score) — ``bbox_keypoints`` of tester.py:410-485 for every box.
+
+    Device: one-hot maps + blur (mpn_prn_build_maps), ONE PRN forward for all boxes, window scores compacted to per-plane candidate
+    lists (mpn_prn_scores_compact: a few bytes per candidate cross PCIe instead of 274 KB of tables per box).  Host: the greedy
+    matching in C++ (mpn_prn_match_host).  (image, joint type) pairs whose result would hinge on numpy's ordering of equal scores,
+    and planes with more than CAND_CAP candidates, take the full-table numpy path below (``fast=False`` forces it everywhere)."""
+    h, w = 56, 36
     dev = next(model.parameters()).device
-    peaks_all = [_peaks_by_joint(k) for k in kps_list]
-    boxes_all = [[[b[0], b[1], b[2] - b[0], b[3] - b[1]] for b in bl] for bl in bbox_lists]        # tester.py:355-357
-    results = [[] for _ in range(nimg)]
-    # flat device inputs: peaks grouped by image then joint type, boxes with their image index
-    flat_peaks, joint_off, flat_boxes, box_img, box_slices = [], [], [], [], []
-    for i in range(nimg):
-        offs = []
-        for j in range(17):
-            offs.append(len(flat_peaks))
-            flat_peaks += [(p[0], p[1]) for p in peaks_all[i][j]]
-        offs.append(len(flat_peaks))
-        joint_off.append(offs)
-        box_slices.append((len(flat_boxes), len(flat_boxes) + len(boxes_all[i])))
-        for b in boxes_all[i]:
-            if math.ceil(b[2]) == 0 or math.ceil(b[3]) == 0:
-                raise ZeroDivisionError("box with zero width/height (the reference divides by ceil(w), tester.py:374)")
-            flat_boxes.append(b)
-            box_img.append(i)
-    nb = len(flat_boxes)
+    nimg = int(box_start.shape[0]) - 1
+    nb = int(boxes_xywh.shape[0])
+    out_kp = np.zeros((nb, 17, 3))
     if nb == 0:
-        return results                                     # tester.py:359-360
-    peaks_t = torch.tensor(flat_peaks if flat_peaks else [[0.0, 0.0]], dtype=torch.float64).to(dev)
-    off_t = torch.tensor(joint_off, dtype=torch.int32).to(dev)
-    boxes_t = torch.tensor(flat_boxes, dtype=torch.float64).to(dev)
-    bimg_t = torch.tensor(box_img, dtype=torch.int32).to(dev)
+        return out_kp
+    if np.any(np.ceil(boxes_xywh[:, 2]) == 0) or np.any(np.ceil(boxes_xywh[:, 3]) == 0):
+        raise ZeroDivisionError("box with zero width/height (the reference divides by ceil(w), tester.py:374)")
+    box_img = np.repeat(np.arange(nimg, dtype=np.int32), np.diff(box_start)).astype(np.int32)
+    peaks_host = np.ascontiguousarray(peaks_xy, dtype=np.float64) if peaks_xy.shape[0] else np.zeros((1, 2))
+    peaks_t = torch.from_numpy(peaks_host).to(dev)
+    off_t = torch.from_numpy(np.ascontiguousarray(joint_off, dtype=np.int32)).to(dev)
+    boxes_t = torch.from_numpy(np.ascontiguousarray(boxes_xywh, dtype=np.float64)).to(dev)
+    bimg_t = torch.from_numpy(box_img).to(dev)
     w9_t = torch.from_numpy(_W9).to(dev)
     occ = torch.empty((nb, 17, h, w), dtype=torch.int32, device=dev)
     prn_in = torch.empty((nb, h, w, 17), dtype=torch.float32, device=dev)
-    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    err = torch.zeros(2, dtype=torch.int32, device=dev)             # [0]: IndexError of the clamp chain, [1]: candidate overflow
     call("mpn_prn_build_maps", ops.ptr(peaks_t), ops.ptr(off_t), ops.ptr(boxes_t), ops.ptr(bimg_t), nb, h, w, float(in_thres), ops.ptr(w9_t),
          ops.ptr(occ), ops.ptr(prn_in), ops.ptr(err), ops.stream_ptr())
     was_training = model.prn.training
@@ -86,25 +87,85 @@ def prn_process_batch(model, kps_list, bbox_lists, file_names=None, image_ids=No
     finally:
         model.prn.train(was_training)
     out = out.detach().float().contiguous()
-    score = torch.zeros((nb, 17, h, w), dtype=torch.float32, device=dev)
+
+    def full_tables(b0, b1, img):
+        """tester.py:410-485 through the full score / occupancy tables of boxes b0..b1 (numpy; exact in every tie)."""
+        n = b1 - b0
+        score = torch.zeros((n, 17, h, w), dtype=torch.float32, device=dev)
+        amax = torch.empty((n, 17), dtype=torch.int32, device=dev)
+        call("mpn_prn_scores", ops.ptr(out[b0:b1]), ops.ptr(occ[b0:b1]), n, h, w, 15, ops.ptr(score), ops.ptr(amax), ops.stream_ptr())
+        offs = joint_off[img]
+        peaks = [[[peaks_host[q, 0], peaks_host[q, 1], 1, q - offs[0]] for q in range(offs[t], offs[t + 1])] for t in range(17)]
+        return _assign(peaks, [list(bx) for bx in boxes_xywh[b0:b1]], occ[b0:b1].cpu().numpy(), score.cpu().numpy(), amax.cpu().numpy(), w, h)
+
+    if not fast:
+        if int(err[0].item()):
+            raise IndexError("a peak falls outside the 56x36 map after the reference's clamp chain (tester.py:376-392 raises here too)")
+        for i in range(nimg):
+            if box_start[i + 1] > box_start[i]:
+                out_kp[box_start[i]:box_start[i + 1]] = full_tables(int(box_start[i]), int(box_start[i + 1]), i)
+        return out_kp
+    cap = CAND_CAP
+    cand_n = torch.empty((nb, 17), dtype=torch.int32, device=dev)
+    cand_id = torch.empty((nb, 17, cap), dtype=torch.int32, device=dev)
+    cand_sc = torch.empty((nb, 17, cap), dtype=torch.float32, device=dev)
     amax = torch.empty((nb, 17), dtype=torch.int32, device=dev)
-    call("mpn_prn_scores", ops.ptr(out), ops.ptr(occ), nb, h, w, 15, ops.ptr(score), ops.ptr(amax), ops.stream_ptr())
-    occ_h, score_h, amax_h, err_h = occ.cpu().numpy(), score.cpu().numpy(), amax.cpu().numpy(), int(err.item())
-    if err_h:
+    call("mpn_prn_scores_compact", ops.ptr(out), ops.ptr(occ), nb, h, w, 15, cap, ops.ptr(cand_n), ops.ptr(cand_id), ops.ptr(cand_sc),
+         ops.ptr(amax), ctypes.c_void_p(err.data_ptr() + 4), ops.stream_ptr())
+    cand_n_h, cand_id_h, cand_sc_h, amax_h, err_h = cand_n.cpu().numpy(), cand_id.cpu().numpy(), cand_sc.cpu().numpy(), amax.cpu().numpy(), err.cpu().numpy()
+    if err_h[0]:
         raise IndexError("a peak falls outside the 56x36 map after the reference's clamp chain (tester.py:376-392 raises here too)")
+    ties = np.zeros((nimg, 17), dtype=np.uint8)
+    bs = np.ascontiguousarray(box_start, dtype=np.int32)
+    bx = np.ascontiguousarray(boxes_xywh, dtype=np.float64)
+    jo = np.ascontiguousarray(joint_off, dtype=np.int32)
+
+    def hp(a):
+        return ctypes.c_void_p(a.ctypes.data)
+    call("mpn_prn_match_host", nimg, hp(bs), hp(bx), hp(jo), hp(peaks_host), hp(cand_n_h), hp(cand_id_h), hp(cand_sc_h), cap, hp(amax_h), h, w,
+         hp(out_kp), hp(ties))
+    redo = set(np.nonzero(ties.any(axis=1))[0].tolist())
+    if err_h[1]:                                               # a plane with more candidates than the compact list holds
+        over = np.nonzero((cand_n_h > cap).any(axis=1))[0]
+        redo.update(int(box_img[b]) for b in over)
+    for i in sorted(redo):
+        out_kp[bs[i]:bs[i + 1]] = full_tables(int(bs[i]), int(bs[i + 1]), i)
+    return out_kp
+
+
+def prn_process_batch(model, kps_list, bbox_lists, file_names=None, image_ids=None, coeff=2, in_thres=0.21, fast=True):
+    nimg = len(kps_list)
+    file_names = file_names if file_names is not None else [""] * nimg
+    image_ids = image_ids if image_ids is not None else [0] * nimg
+    w, h = int(18 * coeff), int(28 * coeff)
+    if (h, w) != (56, 36):
+        raise MpnError("the reference reshapes the PRN output to (56, 36, 17) (tester.py:404): coeff must be 2")
+    peaks_all = [_peaks_by_joint(k) for k in kps_list]
+    boxes_all = [[[b[0], b[1], b[2] - b[0], b[3] - b[1]] for b in bl] for bl in bbox_lists]        # tester.py:355-357
+    results = [[] for _ in range(nimg)]
+    flat_peaks, joint_off, flat_boxes, box_start = [], [], [], [0]
     for i in range(nimg):
-        s, e = box_slices[i]
-        if e == s:
-            continue
-        bk = _assign(peaks_all[i], boxes_all[i], occ_h[s:e], score_h[s:e], amax_h[s:e], w, h)
-        for bi in range(e - s):                              # tester.py:487-511
+        offs = []
+        for j in range(17):
+            offs.append(len(flat_peaks))
+            flat_peaks += [(p[0], p[1]) for p in peaks_all[i][j]]
+        offs.append(len(flat_peaks))
+        joint_off.append(offs)
+        flat_boxes += boxes_all[i]
+        box_start.append(len(flat_boxes))
+    if not flat_boxes:
+        return results                                     # tester.py:359-360
+    bk = prn_assign_arrays(model, np.asarray(flat_peaks, dtype=np.float64).reshape(-1, 2), np.asarray(joint_off, dtype=np.int32),
+                           np.asarray(flat_boxes, dtype=np.float64).reshape(-1, 4), np.asarray(box_start, dtype=np.int32), in_thres, fast)
+    for i in range(nimg):
+        for bi in range(box_start[i], box_start[i + 1]):     # tester.py:487-511
             k = np.zeros(51)
             k[0::3], k[1::3], k[2::3] = bk[bi, :, 0], bk[bi, :, 1], bk[bi, :, 2]
             pose_score = 0
             for f in range(17):
                 pose_score += bk[bi, f, 2]
             pose_score /= 17.0
-            results[i].append({'image_id': image_ids[i], 'file_name': file_names[i], 'category_id': 1, 'bbox': boxes_all[i][bi],
+            results[i].append({'image_id': image_ids[i], 'file_name': file_names[i], 'category_id': 1, 'bbox': boxes_all[i][bi - box_start[i]],
                                'score': pose_score, 'keypoints': k.tolist()})
     return results
 

@@ -77,6 +77,45 @@ def NMS_batch(param, pred, upsampFactor=1., bool_refine_center=True, cap=None):
     return _extract(pred, param['thre1'], upsampFactor, bool_refine_center, cap)
 
 
+def NMS_batch_arrays(param, pred, upsampFactor=1., bool_refine_center=True, cap=None):
+    """NMS_batch without the per-image / per-joint Python lists: (peaks float64 [B, J, most, 4] = (x, y, score, id), counts int32 [B, J])
+    on the host — entries [b, j, :counts[b, j]] are image b's peaks of joint type j in row-major order."""
+    grow = cap is None
+    cap = DEFAULT_CAP if cap is None else cap
+    pk, cnt = _peaks_device(pred, param['thre1'], upsampFactor, bool_refine_center, cap)
+    counts = cnt.cpu().numpy()
+    most = int(counts.max(initial=0))
+    if most > cap:
+        if not grow:
+            raise MpnError("more than %d peaks of one joint type in an image; raise `cap`" % cap)
+        cap = 1 << (most - 1).bit_length()
+        pk, cnt = _peaks_device(pred, param['thre1'], upsampFactor, bool_refine_center, cap)
+        counts = cnt.cpu().numpy()
+    return pk[:, :, :max(most, 1)].cpu().numpy(), counts
+
+
+def body_peaks_flat(peaks, counts, scale=1.0, keep=None):
+    """The 17 body joint types of tester.py:158-164 (the neck, type 1, dropped; later types shifted down) as the flat arrays
+    evaluate.prn_process.prn_assign_arrays takes: (peaks_xy float64 [Np, 2] grouped by image then type, joint_off int32 [B, 18]).
+    `keep`: at most that many peaks per type (in detection order).  Vectorised: no Python loop over peaks."""
+    B, J, M, _ = peaks.shape
+    types = [0] + list(range(2, J))                       # 17 body types in PRN order
+    cnt = counts[:, types].astype(np.int64)
+    if keep is not None:
+        cnt = np.minimum(cnt, keep)
+        peaks, M = peaks[:, :, :keep], min(M, keep)
+    sel = np.arange(M)[None, None, :] < cnt[:, :, None]                       # [B, 17, M]
+    xy = peaks[:, types][..., :2] * scale                                       # [B, 17, M, 2]
+    flat = xy[sel]                                                              # row-major: image, type, detection order
+    off = np.zeros((B, 18), dtype=np.int32)
+    csum = np.cumsum(cnt.reshape(-1))
+    off.reshape(-1)[0] = 0
+    starts = np.concatenate([[0], csum])                                        # B*17 + 1 running offsets
+    off[:, :17] = starts[:-1].reshape(B, 17)
+    off[:, 17] = starts[17::17][:B]
+    return np.ascontiguousarray(flat, dtype=np.float64), off
+
+
 def get_joint_list(img_orig, param, heatmaps, scale):
     """joint_utils.py:141-152: rows (x*scale, y*scale, score, id, joint_type)."""
     per_type = NMS(param, heatmaps, img_orig.shape[0] / float(heatmaps.shape[0]))

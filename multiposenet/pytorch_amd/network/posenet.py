@@ -324,6 +324,22 @@ class poseNet(nn.Module):
         [nms_scores, nms_class, boxes]]); entry b equals what the reference returns for image b run alone."""
         return self._entire_net(img_batch, all_images=True)
 
+    def forward_all_images_padded(self, img_batch):
+        """forward_all_images for batched post-processing: (heat-maps [B,18,H/4,W/4], boxes [B,nmax,4], scores [B,nmax], kept) with
+        image b's detections in rows [:kept[b]] (descending score; single class) — no per-image tensors or Python lists."""
+        self._prepare(img_batch)
+        eng = self._engine
+        ctx = Ctx(False)
+        c2, c3, c4, c5 = eng.backbone(ctx, img_batch)
+        kp = eng.kp_pyramid(ctx, c2, c3, c4, c5)
+        det = eng.det_pyramid(ctx, c3, c4, c5)
+        predict_keypoint, _ = eng.keypoint_head(ctx, kp, False)
+        classification, regression = eng.detection_head(ctx, det)
+        self._finish_forward(ctx)
+        transformed_anchors = decode_and_clip(self.anchors(img_batch), regression, img_batch)
+        boxes, scores, kept = ops.detect_batched(transformed_anchors, classification.reshape(classification.shape[0], -1), 0.05, 0.5, padded=True)
+        return predict_keypoint, boxes, scores, kept
+
     def _entire_net(self, img_batch, all_images):
         self._prepare(img_batch)
         eng = self._engine

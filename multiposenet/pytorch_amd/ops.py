@@ -839,10 +839,11 @@ def gather_dets(dets, keep):
     return boxes, scores
 
 
-def detect_batched(boxes, scores, score_thresh, iou_thresh, mode=0, ws_limit=4 << 30):
+def detect_batched(boxes, scores, score_thresh, iou_thresh, mode=0, ws_limit=4 << 30, padded=False):
     """Score filter + per-image NMS + gather for EVERY image of a batch with two host round trips per batch (the candidate
     counts size the NMS launches, the kept counts size the returned tensors) instead of two per image.
-    boxes [B,A,4], scores [B,A] (f32, contiguous).  Returns per image (boxes[k,4], scores[k]) device tensors (views)."""
+    boxes [B,A,4], scores [B,A] (f32, contiguous).  Returns per image (boxes[k,4], scores[k]) device tensors (views); with
+    padded=True the batch-wide tensors themselves: (boxes [B,nmax,4], scores [B,nmax] in descending order, kept counts list)."""
     B, A = scores.shape[0], scores.shape[1]
     dev = scores.device
     dets = torch.empty((B, A, 5), dtype=torch.float32, device=dev)
@@ -851,6 +852,8 @@ def detect_batched(boxes, scores, score_thresh, iou_thresh, mode=0, ws_limit=4 <
     cnt = counts.tolist()                              # host round trip 1
     nmax = max(cnt)
     if nmax == 0:
+        if padded:
+            return torch.zeros((B, 0, 4), dtype=torch.float32, device=dev), torch.zeros((B, 0), dtype=torch.float32, device=dev), [0] * B
         return [(None, None)] * B
     keep = torch.empty((B, nmax), dtype=torch.int64, device=dev)
     num = torch.empty((B,), dtype=torch.int64, device=dev)
@@ -866,6 +869,8 @@ def detect_batched(boxes, scores, score_thresh, iou_thresh, mode=0, ws_limit=4 <
     out_scores = torch.empty((B, nmax), dtype=torch.float32, device=dev)
     call("mpn_gather_dets_batched", ptr(dets), A * 5, ptr(keep), nmax, ptr(num), B, nmax, ptr(out_boxes), ptr(out_scores), nmax, stream_ptr())
     kept = num.tolist()                                # host round trip 2
+    if padded:
+        return out_boxes, out_scores, [k if cnt[b] > 0 else 0 for b, k in enumerate(kept)]
     return [(out_boxes[b, :k], out_scores[b, :k]) if cnt[b] > 0 else (None, None) for b, k in enumerate(kept)]
 
 

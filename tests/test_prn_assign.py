@@ -110,3 +110,57 @@ def test_hip_prn_process_against_the_real_reference_and_the_oracle():
         assert len(batch[ci]) == int(g["n_%d" % ci])
         for r, kp in zip(batch[ci], g["keypoints_%d" % ci]):
             assert np.array_equal(np.array(r["keypoints"]), kp)
+
+
+@pytest.mark.gpu
+def test_compact_candidates_and_cpp_matching_equal_the_full_table_numpy_path():
+    """The fast path of prn_assign_arrays (candidates compacted on the device, greedy matching in C++) against the full-table
+    path that evaluates the reference's own numpy expressions: the real-reference goldens through both, then crowded random
+    scenes (16 images, up to 12 overlapping boxes, up to 40 peaks per joint type, joint types nobody has, duplicate peak
+    positions that produce EXACT score ties -> those pairs must be detected and handed to the numpy path)."""
+    from multiposenet.pytorch_amd.evaluate import prn_process as pp
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    model = poseNet(50, compute_dtype=torch.float32).cuda()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in _prn_weights(model).items()}, strict=False)
+    model.eval()
+    all_kps, all_boxes = [], []
+    for ci, kps, boxes, g in _cases():
+        all_kps.append(kps); all_boxes.append(boxes)
+    for fast in (True, False):
+        batch = pp.prn_process_batch(model, all_kps, all_boxes, fast=fast)
+        for ci, kps, boxes, g in _cases():
+            assert len(batch[ci]) == int(g["n_%d" % ci])
+            for r, kp, sc in zip(batch[ci], g["keypoints_%d" % ci], g["score_%d" % ci]):
+                assert np.array_equal(np.array(r["keypoints"]), kp) and r["score"] == sc, "fast=%s case %d" % (fast, ci)
+    rs = np.random.RandomState(77)
+    nimg = 16
+    peaks, joint_off, boxes, box_start = [], [], [], [0]
+    for i in range(nimg):
+        nbx = rs.randint(0, 13)
+        for _ in range(nbx):
+            cx, cy, bw, bh = rs.uniform(100, 540), rs.uniform(100, 380), rs.uniform(40, 200), rs.uniform(80, 300)
+            boxes.append([cx - bw / 2, cy - bh / 2, bw, bh])
+        box_start.append(len(boxes))
+        offs = []
+        for t in range(17):
+            offs.append(len(peaks))
+            n = 0 if (t in (4, 11) and i % 3 == 0) else rs.randint(1, 41)
+            pts = np.stack([rs.uniform(0, 640, n), rs.uniform(0, 480, n)], 1)
+            if i % 4 == 1 and n > 4:
+                pts[3] = pts[1]                     # a duplicated peak: same cell for every box -> later overwrites earlier
+            peaks += pts.tolist()
+        offs.append(len(peaks))
+        joint_off.append(offs)
+    args = (np.asarray(peaks, dtype=np.float64), np.asarray(joint_off, dtype=np.int32), np.asarray(boxes, dtype=np.float64).reshape(-1, 4),
+            np.asarray(box_start, dtype=np.int32))
+    fast = pp.prn_assign_arrays(model, *args, fast=True)
+    full = pp.prn_assign_arrays(model, *args, fast=False)
+    assert fast.shape == full.shape == (len(boxes), 17, 3)
+    assert np.array_equal(fast, full), "fast path differs from the full-table numpy path in %d boxes" % int((fast != full).any(axis=(1, 2)).sum())
+    # a tiny candidate capacity forces the overflow fallback everywhere: still the same answer
+    old = pp.CAND_CAP
+    pp.CAND_CAP = 2
+    try:
+        assert np.array_equal(pp.prn_assign_arrays(model, *args, fast=True), full)
+    finally:
+        pp.CAND_CAP = old

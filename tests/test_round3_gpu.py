@@ -540,3 +540,46 @@ def test_relu_backward_in_the_producing_dgrad_epilogue(dtype, pyramid):
     w = m.regressionModel.conv2.weight
     assert float(w.grad.abs().max()) > 0
     report("ReLU backward fused into the producing dgrad (%s, %s towers): train_both step bit-identical" % (str(dtype), "pyramid" if pyramid else "per-level"))
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE config 5 end to end
+def test_cfg5_chain_batch64_f16_equals_per_image_inference():
+    """BASELINE config 5, the whole chain at its batch size: R101 `both` inference 640x640, 64 images, fp16, decode + NMS for every
+    image, heat-map peaks, ONE batched PRN forward, candidate compaction on the device and the C++ matching
+    (Tester.infer_images_batched).  The detector's output bias of the random-weight network is shifted so that people are
+    "detected" (a few boxes per image above 0.5), the PRN has seeded weights.  Size-independent check at FULL size: the batched
+    result dicts of six sampled images equal `Tester.infer_image` run on each alone (the reference semantics, tester.py:194-245) —
+    boxes, scores and all 51 keypoint numbers."""
+    from multiposenet.pytorch_amd.evaluate.tester import Tester, TestParams
+    from oracle import weightgen
+    m = get_model(101, torch.float16)
+    sd = weightgen.gen_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items() if k.startswith("prn.")}, seed=3, flavour="he")
+    m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    m.eval()
+    B, S = 64, 640
+    rs = np.random.RandomState(5)
+    sizes = [(S, S)] * 60 + [(480, 640), (640, 400), (333, 500), (512, 512)]          # mixed sizes share the 640x640 forward
+    images = [rs.uniform(0, 255, (h, w, 3)).astype(np.float32) for h, w in sizes]
+    tp = TestParams()
+    tp.ckpt, tp.inp_size = None, S
+    tester = Tester(m, tp)
+    # shift the classification bias so that roughly 4 anchors per image survive NMS above 0.5
+    with torch.no_grad():
+        _, (cls, _, _) = m([torch.zeros(2, 3, S, S, device="cuda").normal_(), "detection_subnet"])
+        s_ = cls.float().flatten().clamp(1e-6, 1 - 1e-6)
+        q = torch.quantile(s_[torch.randperm(s_.numel(), device=s_.device)[:500000]], 1.0 - 40.0 / float(cls.shape[1]))
+        old_bias = m.classificationModel.output.bias.data.clone()
+        m.classificationModel.output.bias.data += float(-torch.log(q / (1 - q)))
+    try:
+        res = tester.infer_images_batched(images, ["f%d.jpg" % i for i in range(B)], list(range(B)), batch=64)
+        assert len(res) == B
+        nboxes = sum(len(r) for r in res)
+        assert nboxes >= 32, "the calibrated detector should find people (%d boxes in 64 images)" % nboxes
+        for i in (0, 7, 31, 60, 61, 62):
+            single = tester.infer_image(images[i], "f%d.jpg" % i, i)
+            assert len(single) == len(res[i]), "image %d: %d vs %d people" % (i, len(single), len(res[i]))
+            for a, b in zip(single, res[i]):
+                assert a["bbox"] == b["bbox"] and a["score"] == b["score"] and a["keypoints"] == b["keypoints"] and a["image_id"] == b["image_id"], i
+    finally:
+        m.classificationModel.output.bias.data.copy_(old_bias)
+    report("cfg5 chain (R101 640x640 B=64 f16): %d people in 64 images; batched Tester results identical to per-image inference on 6 sampled images" % nboxes)

@@ -20,11 +20,12 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"])
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-fold", action="store_true")
+    ap.add_argument("--people", type=int, default=4, help="boxes per image handed to the PRN assignment / peaks per joint plane the calibrated threshold keeps")
     ap.add_argument("--candidates", type=int, default=1000, help="anchors per image above the 0.05 score threshold (the classification bias "
                     "of the random-weight network is shifted to get there; a trained detector passes a few hundred)")
     args = ap.parse_args()
-    from multiposenet.pytorch_amd.evaluate.prn_process import prn_process_batch
-    from multiposenet.pytorch_amd.network.joint_utils import NMS_batch
+    from multiposenet.pytorch_amd.evaluate.prn_process import prn_assign_arrays, prn_process_batch
+    from multiposenet.pytorch_amd.network.joint_utils import NMS_batch, NMS_batch_arrays, body_peaks_flat
     from multiposenet.pytorch_amd.network.posenet import poseNet
     from oracle import weightgen
     import bench
@@ -68,8 +69,31 @@ def main():
             bx = dets[b][2][dets[b][0] > 0.5][:8] if dets[b][0].numel() else []
             boxes.append([[float(v) for v in bb] for bb in bx if bb[2] - bb[0] >= 1 and bb[3] - bb[1] >= 1])
         return prn_process_batch(m, kps, boxes)
+    # random-weight heat-maps are noise (hundreds of peaks per joint plane, each with its bicubic refinement): the peak threshold is
+    # calibrated so that about `--people` peaks per plane survive, which is what the reference's 0.1 leaves on a trained model
+    with torch.no_grad():
+        h0, _ = m.forward_all_images(img[:4].contiguous())
+    hv = h0.float().flatten()
+    thre1 = float(torch.quantile(hv[torch.randperm(hv.numel(), device=hv.device)[:2000000]], 1.0 - args.people * 12.0 / (h0.shape[2] * h0.shape[3])))
+
+    def full_arrays():
+        """The chain on flat arrays: padded batch detections, peaks as one array, candidates compacted on the device, matching in
+        C++ (prn_assign_arrays); the 8 best NMS survivors of every image stand in for its people (no random-weight score exceeds
+        0.5).  Returns keypoints [boxes, 17, 3]."""
+        with torch.no_grad():
+            heat, boxes, scores, kept = m.forward_all_images_padded(img)
+        pk, cnt = NMS_batch_arrays({'thre1': thre1}, heat, 4.0)
+        peaks_xy, joint_off = body_peaks_flat(pk, cnt, keep=args.people)     # ... and at most `people` peaks per joint type reach the PRN stage
+        nb = np.minimum(np.asarray(kept), args.people)
+        sel = np.arange(boxes.shape[1])[None, :] < nb[:, None]
+        b4 = boxes[:, :4].double().cpu().numpy()[sel[:, :4]]
+        b4[:, 2:] -= b4[:, :2]                                                   # (x1, y1, x2, y2) -> (x, y, w, h)
+        ok = (b4[:, 2] >= 1) & (b4[:, 3] >= 1)
+        start = np.concatenate([[0], np.cumsum(np.add.reduceat(ok, np.concatenate([[0], np.cumsum(nb)[:-1]])) if ok.size else nb * 0)]).astype(np.int32)
+        return prn_assign_arrays(m, peaks_xy, joint_off, b4[ok], start)
     for name, fn in (("network only (backbone, both pyramids, both heads)", net_only), ("network + decode + NMS for every image", net),
-                     ("+ heat-map peaks + PRN assignment", full)):
+                     ("+ heat-map peaks + PRN assignment, reference list interface, threshold 0.1 (noise: hundreds of peaks per plane)", full),
+                     ("+ heat-map peaks + PRN assignment (%d people / image; flat arrays, compact candidates, C++ matching)" % args.people, full_arrays)):
         fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
