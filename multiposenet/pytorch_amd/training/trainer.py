@@ -318,9 +318,6 @@ class Trainer(object):
         self._apply_train_modes()
         self._step = _Stepper(self.model, self.optimizer, p)
         self._lazy = bool(p.lazy_log) and hasattr(self.model, '_engine')
-        if self._lazy:
-            from ..network import losses
-            losses.set_lazy_log(True)
 
     # ------------------------------------------------------------------ modes / resume
     def _apply_train_modes(self):
@@ -351,6 +348,19 @@ class Trainer(object):
         return epoch % p.save_freq_epoch == 0 or epoch == p.max_epoch - 1
 
     def train(self):
+        """All remaining epochs.  While it runs, loss log values are asynchronous proxies (losses.set_lazy_log) unless
+        ``params.lazy_log`` is off; the process-wide setting is restored on the way out."""
+        if not self._lazy:
+            return self._train()
+        from ..network import losses
+        before = losses.LAZY_LOG
+        losses.set_lazy_log(True)
+        try:
+            return self._train()
+        finally:
+            losses.set_lazy_log(before)
+
+    def _train(self):
         p = self.params
         best = INF
         while self.last_epoch < p.max_epoch:

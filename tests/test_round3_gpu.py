@@ -134,6 +134,7 @@ def test_trainer_uses_the_recorded_step_and_tester_val_matches_a_hand_loop(tmp_p
     try:
         tr = Trainer(model, P, batch_processor, train_data, None)
         tr.train()
+        assert losses.LAZY_LOG == was_lazy, "Trainer.train() must restore the process-wide lazy-log setting"
         torch.cuda.synchronize()
         assert tr._step.fast is not None and tr._step.fast.replays == 3       # 1 eager + 1 recording + 3 replays
         assert torch.equal(model._arena.flat, want), "Trainer's recorded steps differ from the hand-written eager loop"
