@@ -308,6 +308,18 @@ int mpn_mse_heatmap_backward(const float* const* preds, float* const* dpreds, co
                              const int64_t* dpred_sP, const int32_t* pred_C, const float* gt, const float* wgt,
                              int64_t npix, const float* gscale, void* stream);
 int mpn_mse_chunks(int64_t npix);
+/* The recorded training step's form of the two calls above (replay.py): loss and gradients in ONE pass over the network's
+ * internal tensors, with no exported f32 copies.  levels[0..3] = the intermediate maps k2..k5 (f32, [B, H>>s, W>>s, 32], s = 0..3:
+ * posenet.py:243-257 up-samples them by nearest neighbours to the heat-map size, so pixel (y, x) reads level s at (y>>s, x>>s) and
+ * a coarse cell's gradient is the sum over its children), levels[4] = the final prediction at [B, H, W, 32]; dlevels[j] receives
+ * d(total)/d(levels[j]) in `dtype` with the padding channels zero.  gt / wgt are the reference's NCHW f32 targets read in place
+ * (strides g_sB, g_sC, g_sH in elements, unit stride along x).  H and W must be multiples of 8.  out as for
+ * mpn_mse_heatmap_forward; partial needs blocks * 8 floats, blocks = mpn_mse_train_blocks(B, H, W).  The gradients are
+ * bit-identical to mpn_mse_heatmap_backward + mpn_import_grad. */
+int mpn_mse_train_blocks(int B, int H, int W);
+int mpn_mse_heatmap_train(const float* const* levels, void* const* dlevels, const int32_t* level_Cs, int dtype,
+                          const float* gt, const float* wgt, int64_t g_sB, int64_t g_sC, int64_t g_sH,
+                          int B, int H, int W, const float* gscale, float* partial, int blocks, float* out, void* stream);
 /* focal + smooth-L1.  cls [B,A] f32 (post-sigmoid), reg [B,A,4], anchors [A,4], anno [B,maxN,5].
  * out[0] = cls loss, out[1] = reg loss (batch means).  per_img [B][4] scratch. */
 int mpn_focal_blocks(int A);   /* partial needs B * mpn_focal_blocks(A) * 4 floats */

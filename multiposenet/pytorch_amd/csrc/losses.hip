@@ -96,6 +96,18 @@ __global__ void mse_finalize_kernel(const float* __restrict__ partial, int chunk
     }
 }
 
+// d(total)/d(pred_j) at one full-resolution element.  Contraction is off so that mse_bwd_kernel (API path: full-resolution f32
+// gradients, summed onto the coarser levels by import_grad) and mse_train_kernel (recorded step: the same sums inside one launch)
+// round identically; the recorded step's parameters then stay bit-identical to the eager step's.
+__device__ __forceinline__ float mse_grad(float k, float w, float g, float pv) {
+#pragma clang fp contract(off)
+    const float a = pv * w;
+    const float b = w * g;
+    const float d = a - b;
+    const float kw = k * w;
+    return kw * d;
+}
+
 // one thread per (pixel, channel < Cmax); dpred_j[pix*sP + c] = gs*2*w*(p*w - w*g)/N, 0 for c >= 18
 __global__ void mse_bwd_kernel(PredPtrs pr, DPredPtrs dp, const float* __restrict__ gt, const float* __restrict__ wgt,
                                long npix, int Cmax, const float* __restrict__ gscale) {
@@ -110,11 +122,123 @@ __global__ void mse_bwd_kernel(PredPtrs pr, DPredPtrs dp, const float* __restric
     for (int j = 0; j < 5; ++j) {
         if (c >= dp.C[j] || dp.p[j] == nullptr) continue;
         float v = 0.f;
-        if (c < 18) {
-            const float pv = pr.p[j][pix * pr.sP[j] + c];
-            v = k * w * (pv * w - w * g);
-        }
+        if (c < 18) v = mse_grad(k, w, g, pr.p[j][pix * pr.sP[j] + c]);
         dp.p[j][pix * dp.sP[j] + c] = v;
+    }
+}
+
+// ---- recorded training step: loss AND gradients in one pass over the INTERNAL tensors (no exported f32 copies) --------------
+// Levels 0..3 are the intermediate maps k2..k5 at 1, 1/2, 1/4, 1/8 of the heat-map resolution (posenet.py:243-257 up-samples them
+// with nearest neighbours, so a full-resolution pixel (y, x) reads level s at (y >> s, x >> s) and the gradient of a coarse cell is
+// the sum over its 4^s children); level 4 is the final prediction.  One thread owns (8x8 pixel cell, channel): it walks its 64
+// pixels in row-major order, which is the order import_grad_kernel sums children in, so the coarse gradients round identically.
+// Block = 8 cells x 32 channel lanes; lanes >= 18 write the zero padding of the gradient tensors.
+struct TrainPtrs { const float* p[5]; void* d[5]; int Cs[5]; };
+
+template <typename T>
+__global__ void __launch_bounds__(256) mse_train_kernel(TrainPtrs tp, const float* __restrict__ gt, const float* __restrict__ wgt,
+                                                        long g_sB, long g_sC, long g_sH, int B, int H, int W, long ncell,
+                                                        const float* __restrict__ gscale, float* __restrict__ partial) {
+    __shared__ float sh[4][8];
+    const int c = threadIdx.x & 31;
+    const long cell = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float mx = -INFINITY, mn = INFINITY;
+    if (cell < ncell) {
+        const int cw = W >> 3, ch = H >> 3;
+        const int cx = (int)(cell % cw);
+        const int cy = (int)((cell / cw) % ch);
+        const int b = (int)(cell / ((long)cw * ch));
+        const int y0 = cy * 8, x0 = cx * 8;
+        const float gs = gscale ? gscale[0] : 1.f;
+        const float k = gs * 2.0f / (float)((double)B * H * W * 18.0);
+        const bool live = c < 18;
+        T* d0 = (T*)tp.d[0]; T* d1 = (T*)tp.d[1]; T* d2 = (T*)tp.d[2]; T* d3 = (T*)tp.d[3]; T* d4 = (T*)tp.d[4];
+        float pv1[4] = {0.f, 0.f, 0.f, 0.f}, pv2[2] = {0.f, 0.f}, pv3 = 0.f;
+        float a1[4], a2[2], a3 = 0.f;
+        if (live) pv3 = tp.p[3][(((long)b * ch + cy) * cw + cx) * tp.Cs[3] + c];
+        for (int r = 0; r < 8; ++r) {
+            const int y = y0 + r;
+            float g[8], w[8];
+            if (live) {
+                const float* gp = gt + b * g_sB + c * g_sC + y * g_sH + x0;
+                const float* wp = wgt + b * g_sB + c * g_sC + y * g_sH + x0;
+                const float4 ga = *(const float4*)gp, gb = *(const float4*)(gp + 4);
+                const float4 wa = *(const float4*)wp, wb = *(const float4*)(wp + 4);
+                g[0] = ga.x; g[1] = ga.y; g[2] = ga.z; g[3] = ga.w; g[4] = gb.x; g[5] = gb.y; g[6] = gb.z; g[7] = gb.w;
+                w[0] = wa.x; w[1] = wa.y; w[2] = wa.z; w[3] = wa.w; w[4] = wb.x; w[5] = wb.y; w[6] = wb.z; w[7] = wb.w;
+                if ((r & 1) == 0) {
+                    const float* q = tp.p[1] + (((long)b * (H >> 1) + (y >> 1)) * (W >> 1) + (x0 >> 1)) * tp.Cs[1] + c;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { pv1[i] = q[(long)i * tp.Cs[1]]; a1[i] = 0.f; }
+                }
+                if ((r & 3) == 0) {
+                    const float* q = tp.p[2] + (((long)b * (H >> 2) + (y >> 2)) * (W >> 2) + (x0 >> 2)) * tp.Cs[2] + c;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) { pv2[i] = q[(long)i * tp.Cs[2]]; a2[i] = 0.f; }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { g[i] = 0.f; w[i] = 0.f; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a1[i] = 0.f;
+                a2[0] = a2[1] = 0.f;
+            }
+            const long row = ((long)b * H + y) * W + x0;
+#pragma unroll
+            for (int px = 0; px < 8; ++px) {
+                float v0 = 0.f, v4 = 0.f;
+                if (live) {
+                    const float p0 = tp.p[0][(row + px) * tp.Cs[0] + c];
+                    const float p4 = tp.p[4][(row + px) * tp.Cs[4] + c];
+                    const float wv = w[px], gv = g[px];
+                    const float wg = wv * gv;
+                    float e;
+                    e = p0 * wv - wg;      s[0] += e * e;
+                    e = pv1[px >> 1] * wv - wg; s[1] += e * e;
+                    e = pv2[px >> 2] * wv - wg; s[2] += e * e;
+                    e = pv3 * wv - wg;     s[3] += e * e;
+                    e = p4 * wv - wg;      s[4] += e * e;
+                    mx = fmaxf(mx, p4); mn = fminf(mn, p4);
+                    v0 = 0.f + mse_grad(k, wv, gv, p0);
+                    v4 = 0.f + mse_grad(k, wv, gv, p4);
+                    a1[px >> 1] += mse_grad(k, wv, gv, pv1[px >> 1]);
+                    a2[px >> 2] += mse_grad(k, wv, gv, pv2[px >> 2]);
+                    a3 += mse_grad(k, wv, gv, pv3);
+                }
+                Elem<T>::st(d0 + (row + px) * tp.Cs[0] + c, v0);
+                Elem<T>::st(d4 + (row + px) * tp.Cs[4] + c, v4);
+            }
+            if (r & 1) {
+                T* q = d1 + (((long)b * (H >> 1) + (y >> 1)) * (W >> 1) + (x0 >> 1)) * tp.Cs[1] + c;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Elem<T>::st(q + (long)i * tp.Cs[1], a1[i]);
+            }
+            if ((r & 3) == 3) {
+                T* q = d2 + (((long)b * (H >> 2) + (y >> 2)) * (W >> 2) + (x0 >> 2)) * tp.Cs[2] + c;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) Elem<T>::st(q + (long)i * tp.Cs[2], a2[i]);
+            }
+        }
+        Elem<T>::st(d3 + (((long)b * ch + cy) * cw + cx) * tp.Cs[3] + c, a3);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) s[j] = wave_sum(s[j]);
+    mx = wave_max(mx); mn = wave_min(mn);
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) sh[wave][j] = s[j];
+        sh[wave][6] = mx; sh[wave][7] = mn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* o = partial + (long)blockIdx.x * 8;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) o[j] = sh[0][j] + sh[1][j] + sh[2][j] + sh[3][j];
+        o[5] = 0.f;
+        o[6] = fmaxf(fmaxf(sh[0][6], sh[1][6]), fmaxf(sh[2][6], sh[3][6]));
+        o[7] = fminf(fminf(sh[0][7], sh[1][7]), fminf(sh[2][7], sh[3][7]));
     }
 }
 
@@ -399,6 +523,27 @@ extern "C" int mpn_mse_heatmap_backward(const float* const* preds, float* const*
     }
     const long n = (long)npix * cmax;
     hipLaunchKernelGGL(mse_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pr, dp, gt, wgt, (long)npix, cmax, gscale);
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_mse_train_blocks(int B, int H, int W) { return (int)(((long)B * (H / 8) * (W / 8) + 7) / 8); }
+
+extern "C" int mpn_mse_heatmap_train(const float* const* levels, void* const* dlevels, const int32_t* level_Cs, int dtype,
+                                     const float* gt, const float* wgt, int64_t g_sB, int64_t g_sC, int64_t g_sH,
+                                     int B, int H, int W, const float* gscale, float* partial, int blocks, float* out, void* stream) {
+    MPN_CHECK_ARG(levels && dlevels && level_Cs && gt && wgt && partial && out && B > 0);
+    MPN_CHECK_ARG(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && blocks == mpn_mse_train_blocks(B, H, W));
+    MPN_CHECK_ARG(g_sH % 4 == 0 && g_sC % 4 == 0 && g_sB % 4 == 0 && ((uintptr_t)gt & 15) == 0 && ((uintptr_t)wgt & 15) == 0);
+    TrainPtrs tp;
+    for (int j = 0; j < 5; ++j) {
+        MPN_CHECK_ARG(levels[j] && dlevels[j] && level_Cs[j] == 32);
+        tp.p[j] = levels[j]; tp.d[j] = dlevels[j]; tp.Cs[j] = level_Cs[j];
+    }
+    const long ncell = (long)B * (H / 8) * (W / 8);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((mse_train_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tp, gt, wgt,
+                                             (long)g_sB, (long)g_sC, (long)g_sH, B, H, W, ncell, gscale, partial));
+    hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, blocks,
+                       (double)B * H * W * 18.0, out);
     return mpn_launch_status();
 }
 

@@ -691,6 +691,17 @@ class Engine(object):
             ctx.tape.append(bwd)
         return out
 
+    def export_internal(self, ctx, src, slot):
+        """The recorded step's form of export(): no API tensor.  Its loss kernel reads ``src`` itself and puts an internal gradient
+        activation under ``slot`` (losses.mse_train_raw)."""
+        if ctx.train and src.needs_grad:
+            def bwd():
+                g = ctx.out_grads.get(slot)
+                if g is not None:
+                    ctx.set_grad(src, g)
+            ctx.tape.append(bwd)
+        return src
+
     # ------------------------------------------------------------------ network pieces
     def stem(self, ctx, img):
         """conv1 7x7/s2 + bn1 + relu + maxpool (fpn.py:99-100) via the NHWC4 packed row-conv."""
@@ -791,8 +802,9 @@ class Engine(object):
         fp2s, _ = self.conv(ctx, fp2, f.smooth3)
         return [fp2s, fp3s, fp4s, fp5]
 
-    def keypoint_head(self, ctx, feats, intermediate):
-        """posenet.py:288-318 / :243-257.  Returns (pred, [k2,k3,k4,k5]) as f32 API tensors."""
+    def keypoint_head(self, ctx, feats, intermediate, internal=False):
+        """posenet.py:288-318 / :243-257.  Returns (pred, [k2,k3,k4,k5]) as f32 API tensors, or with ``internal`` as the
+        network's own activations at their native resolutions (the recorded step's loss kernel up-samples by indexing)."""
         m = self.m
         p2, p3, p4, p5 = feats
         Ho, Wo = p2.H, p2.W
@@ -800,7 +812,7 @@ class Engine(object):
         if intermediate:
             for i, (src, layer) in enumerate(((p2, m.convfin_k2), (p3, m.convfin_k3), (p4, m.convfin_k4), (p5, m.convfin_k5))):
                 k, _ = self.conv(ctx, src, layer, out_f32=True)
-                saved.append(self.export(ctx, k, 19, Ho, Wo, "k%d" % i))
+                saved.append(self.export_internal(ctx, k, "k%d" % i) if internal else self.export(ctx, k, 19, Ho, Wo, "k%d" % i))
         q5, _ = self.conv(ctx, self.conv(ctx, p5, m.convt1)[0], m.convs1)
         q4, _ = self.conv(ctx, self.conv(ctx, p4, m.convt2)[0], m.convs2)
         q3, _ = self.conv(ctx, self.conv(ctx, p3, m.convt3)[0], m.convs3)
@@ -811,7 +823,7 @@ class Engine(object):
             cat = self.concat_up(ctx, [q5, q4, q3, q2], Ho, Wo)
             h, _ = self.conv(ctx, cat, m.conv2, act=1)
         pr, _ = self.conv(ctx, h, m.convfin, out_f32=True)
-        pred = self.export(ctx, pr, 18, Ho, Wo, "pred")
+        pred = self.export_internal(ctx, pr, "pred") if internal else self.export(ctx, pr, 18, Ho, Wo, "pred")
         return pred, saved
 
     def detection_head(self, ctx, feats):

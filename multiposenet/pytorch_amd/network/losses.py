@@ -60,6 +60,32 @@ def mse_backward_raw(pm, heat, wgt, gs, need):
     return grads
 
 
+def mse_train_supported(levels, heat):
+    """The one-pass form needs every intermediate level at an exact power-of-two fraction of a heat-map whose sides are multiples
+    of 8 (true of the reference's 480x480 / 384x384 training crops), and dense NCHW targets."""
+    B, C, H, W = heat.shape
+    if C != 18 or H % 8 or W % 8 or not heat.is_contiguous():
+        return False
+    geo = [(H >> s, W >> s) for s in (0, 1, 2, 3)] + [(H, W)]
+    return all(a.B == B and (a.H, a.W) == g and a.Cs == 32 and a.t.dtype == torch.float32 for a, g in zip(levels, geo))
+
+
+def mse_train_raw(levels, heat, wgt, gs, dtype):
+    """Recorded step: heat-map loss and its gradients straight from the network's internal tensors.  levels: the five f32
+    activations (k2..k5 at 1, 1/2, 1/4, 1/8 of the heat-map size, then the prediction); heat / wgt: the reference's NCHW f32 targets,
+    read in place.  Returns (out[8] as mse_forward_raw, five internal gradient activations of ``dtype``)."""
+    B, _, H, W = heat.shape
+    dev = heat.device
+    blocks = call("mpn_mse_train_blocks", B, H, W)
+    part = ops.workspace(blocks * 8 * 4, dev, slot=5)
+    out = torch.empty(8, dtype=torch.float32, device=dev)
+    grads = [ops.Act(torch.empty(a.t.shape, dtype=dtype, device=dev), a.C) for a in levels]
+    call("mpn_mse_heatmap_train", _vpx5(*[a.t.data_ptr() for a in levels]), _vpx5(*[g.t.data_ptr() for g in grads]),
+         _i32x5(*[a.Cs for a in levels]), ops.dtype_code(dtype), ops.ptr(heat), ops.ptr(wgt), heat.stride(0), heat.stride(1),
+         heat.stride(2), B, H, W, ops.ptr(gs), ops.ptr(part), blocks, ops.ptr(out), ops.stream_ptr())
+    return out, grads
+
+
 class _HeatmapMSE(torch.autograd.Function):
     """sum_j mean(((pred_j[:, :18] * w) - (w * gt))^2)   (posenet.py:376-387)."""
 

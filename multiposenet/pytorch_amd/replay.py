@@ -20,11 +20,14 @@ Same interface as ``training.batch_processor.train_step`` / ``graph.GraphedTrain
     step = ReplayedTrainStep(model, optimizer)
     loss, saved_for_log = step(inputs, gts)
 
-The result is bit-identical to the eager step (same kernels, same order, same scratch sizes: tests/test_replay_gpu.py).
+The parameters after a step are bit-identical to the eager step's (same kernels, same order, same scratch sizes; the heat-map
+loss runs as one launch over the internal tensors whose gradients round exactly as the API path's export -> loss -> import chain,
+and whose logged loss values agree to f32 summation order: tests/test_replay_gpu.py).
 Re-recorded when the model moves, the set of trainable parameters / BN modes / compute dtype changes, or a new input
 signature arrives.  'prn_subnet' (host-made dropout seeds) and gradient clipping stay on the eager path.
 """
 import itertools
+import os
 from collections import OrderedDict
 
 import torch
@@ -41,9 +44,11 @@ class _Entry(object):
 
 
 class ReplayedTrainStep(object):
-    def __init__(self, model, optimizer, eager_steps=1):
+    def __init__(self, model, optimizer, eager_steps=1, fused_mse=None):
         self.model = model
         self.opt = optimizer
+        # heat-map loss + gradients in one launch over the internal tensors (MPN_FUSED_MSE=0: the API path's kernel chain)
+        self.fused_mse = (os.environ.get("MPN_FUSED_MSE", "1") != "0") if fused_mse is None else bool(fused_mse)
         self.eager_steps = max(1, int(eager_steps))       # steps that fill host-side caches (anchors, transpose table, Adam state)
         self._entries = {}
         self._seen = {}
@@ -64,13 +69,26 @@ class ReplayedTrainStep(object):
         # order in which gradients accumulate into shared feature maps, follows it)
         kp_feats = eng.kp_pyramid(ctx, c2, c3, c4, c5) if want_kp else None
         det_feats = eng.det_pyramid(ctx, c3, c4, c5) if want_det else None
+        # heat-map loss: one launch over the network's internal tensors where the geometry allows (losses.mse_train_supported),
+        # else the API path's export -> loss -> import chain.  Both produce the same gradient bits.
+        fused_mse = False
         if want_kp:
-            pred, saved = eng.keypoint_head(ctx, kp_feats, True)
+            hp = kp_feats[0]
+            fused_mse = self.fused_mse and tensors[0].shape == (hp.B, 18, hp.H, hp.W) and hp.H % 8 == 0 and hp.W % 8 == 0 \
+                and tensors[0].shape == tensors[1].shape
+            pred, saved = eng.keypoint_head(ctx, kp_feats, True, internal=fused_mse)
+            if fused_mse and not losses.mse_train_supported(saved + [pred], tensors[0]):
+                raise _lib.MpnError("recorded train step: the keypoint head's internal geometry does not fit the one-pass loss kernel; "
+                                    "construct ReplayedTrainStep(..., fused_mse=False)")
         if want_det:
             cls, reg = eng.detection_head(ctx, det_feats)
         m._finish_forward(ctx)
         dev = img.device
-        if want_kp:
+        ones = self._ones(dev)
+        if want_kp and fused_mse:      # d(total)/d(heat-map total) = 1, known before the loss value is: gradients in the same pass
+            kp8, kgrads = losses.mse_train_raw(saved + [pred], tensors[0], tensors[1], ones, eng.cdt)
+            grads.update(zip(("k0", "k1", "k2", "k3", "pred"), kgrads))
+        elif want_kp:
             heat = ops.nchw_to_nhwc_f32(tensors[0].detach().float())
             wgt = ops.nchw_to_nhwc_f32(tensors[1].detach().float())
             pm = [losses._pixel_major(p) for p in saved + [pred]]
@@ -81,8 +99,7 @@ class ReplayedTrainStep(object):
         logv = torch.zeros(12, dtype=torch.float32, device=dev)
         _lib.call("mpn_step_log", ops.ptr(kp8), ops.ptr(det2), ops.ptr(logv), ops.stream_ptr())
         self.opt.zero_grad()
-        ones = self._ones(dev)
-        if want_kp:      # d(total)/d(heat-map total) = 1 (posenet.py:387 sums the level losses; the combined step adds the two totals)
+        if want_kp and not fused_mse:      # d(total)/d(heat-map total) = 1 (posenet.py:387 sums the level losses; the combined step adds the two totals)
             for slot, g in zip(("k0", "k1", "k2", "k3", "pred"), losses.mse_backward_raw(pm, heat, wgt, ones, [True] * 5)):
                 grads[slot] = g
         if want_det:     # d(total)/d(cls loss) = d(total)/d(reg loss) = 1 (posenet.py:417-421)

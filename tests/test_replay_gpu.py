@@ -1,6 +1,7 @@
-"""The recorded training step (replay.py) against the eager autograd step: bit-identical parameters, Adam moments, BN
-statistics and log values over several steps with fresh inputs; learning-rate changes; re-recording after a change of
-the trainable set; the single-subnet bodies."""
+"""The recorded training step (replay.py) against the eager autograd step: bit-identical parameters, Adam moments and BN
+statistics over several steps with fresh inputs, log values equal up to the f32 summation order of the heat-map loss (the
+recorded step sums it inside its one-pass loss kernel; MPN_FUSED_MSE=0 makes the logs bit-identical too); learning-rate
+changes; re-recording after a change of the trainable set; the single-subnet bodies."""
 import numpy as np
 import pytest
 import torch
@@ -10,6 +11,16 @@ from test_model_gpu import get_model, t
 from test_round2_gpu import _train_setup
 
 pytestmark = pytest.mark.gpu
+
+
+def _same_logs(a, b, rel=2e-6):
+    """[(loss, values, names)] per step: same names, values within the summation-order tolerance of the heat-map loss."""
+    assert len(a) == len(b)
+    for (la, va, na), (lb, vb, nb) in zip(a, b):
+        assert na == nb
+        for x, y in zip([la] + va, [lb] + vb):
+            assert abs(x - y) <= rel * max(abs(x), abs(y), 1e-30), "log values differ:\n%s\n%s" % (a, b)
+    return True
 
 
 def _run(m, state0, make_step, batches, lr_change_at=None, freeze_at=None):
@@ -58,7 +69,7 @@ def test_replayed_step_is_bit_identical_to_the_eager_autograd_step(subnet):
     eager = _run(m, state0, lambda mm, oo: (lambda a, b: train_step(mm, oo, a, b)), batches, lr_change_at=4)
     rep = _run(m, state0, lambda mm, oo: ReplayedTrainStep(mm, oo), batches, lr_change_at=4)
     assert rep[5].replays == 4                      # one eager pass, one recording, four replays
-    assert eager[4] == rep[4], "log values differ:\n%s\n%s" % (eager[4], rep[4])
+    assert _same_logs(eager[4], rep[4])
     assert torch.equal(eager[0], rep[0]) and torch.equal(eager[1], rep[1]) and torch.equal(eager[2], rep[2])
     assert all(torch.equal(eager[3][k], rep[3][k]) for k in eager[3])
     assert eager[4][0][0] != eager[4][5][0]
@@ -74,6 +85,6 @@ def test_replayed_step_rerecords_when_the_trainable_set_changes():
     state0 = {k: v.clone() for k, v in m.state_dict().items()}
     eager = _run(m, state0, lambda mm, oo: (lambda a, b: train_step(mm, oo, a, b)), batches, freeze_at=3)
     rep = _run(m, state0, lambda mm, oo: ReplayedTrainStep(mm, oo), batches, freeze_at=3)
-    assert torch.equal(eager[0], rep[0]) and eager[4] == rep[4]
+    assert torch.equal(eager[0], rep[0]) and _same_logs(eager[4], rep[4])
     for p in m.parameters():
         p.requires_grad = True

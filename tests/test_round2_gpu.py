@@ -376,7 +376,7 @@ def test_two_rank_recorded_step_equals_the_eager_data_parallel_step():
     for r in range(2):
         assert int(res[r]["replays"]) == 2
         assert np.array_equal(res[r]["eager_params"], res[r]["replay_params"]), "rank %d: recorded step diverged from the eager step" % r
-        assert np.array_equal(res[r]["eager_loss"], res[r]["replay_loss"])
+        assert np.allclose(res[r]["eager_loss"], res[r]["replay_loss"], rtol=2e-6, atol=0)      # heat-map loss: f32 summation order only
     assert np.array_equal(res[0]["replay_params"], res[1]["replay_params"]), "ranks hold different parameters after four steps"
     assert not np.array_equal(res[0]["eager_loss"], res[1]["eager_loss"]), "the two ranks should see different shards"
     report("2-rank recorded step (%s): parameters bit-identical to the eager data-parallel job after 4 steps on both ranks"

@@ -584,3 +584,42 @@ def test_cfg5_chain_batch64_f16_equals_per_image_inference():
     finally:
         m.classificationModel.output.bias.data.copy_(old_bias)
     report("cfg5 chain (R101 640x640 B=64 f16): %d people in 64 images; batched Tester results identical to per-image inference on 6 sampled images" % nboxes)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_one_pass_heatmap_loss_equals_the_export_loss_import_chain(dtype):
+    """losses.mse_train_raw (the recorded step's loss: one launch over the internal tensors, up-sampling by indexing, coarse-level
+    gradients summed in the launch) against the API path's chain on the same tensors — export_f32 (nearest up-sampling,
+    posenet.py:243-257) -> mse_forward_raw / mse_backward_raw (posenet.py:376-387) -> import_grad: gradients bit-identical in every
+    level and padding lane, loss values within f32 summation order, max / min exact."""
+    from multiposenet.pytorch_amd import ops
+    from multiposenet.pytorch_amd.network import losses
+    B, H, W = 3, 24, 40
+    g = torch.Generator().manual_seed(77)
+    levels = []
+    for s, C in ((0, 19), (1, 19), (2, 19), (3, 19), (0, 18)):
+        x = torch.randn(B, H >> s, W >> s, 32, generator=g)
+        x[..., C:] = 0
+        levels.append(ops.Act(x.cuda(), C))
+    heat = torch.rand(B, 18, H, W, generator=g).cuda()
+    wgt = (torch.rand(B, 18, H, W, generator=g) > 0.2).float().cuda() * torch.rand(B, 18, H, W, generator=g).cuda()
+    ones = torch.ones(2, device="cuda")
+    assert losses.mse_train_supported(levels, heat)
+    out1, g1 = losses.mse_train_raw(levels, heat, wgt, ones, dtype)
+    exported = [ops.export_f32(a, a.C, H, W) for a in levels]
+    pm = [losses._pixel_major(p) for p in exported]
+    hn, wn = ops.nchw_to_nhwc_f32(heat), ops.nchw_to_nhwc_f32(wgt)
+    out0 = losses.mse_forward_raw(pm, hn, wn)
+    g0 = [ops.import_grad(gr, a, dtype) for gr, a in zip(losses.mse_backward_raw(pm, hn, wn, ones, [True] * 5), levels)]
+    torch.cuda.synchronize()
+    for j, (a, b) in enumerate(zip(g0, g1)):
+        assert a.t.shape == b.t.shape and a.t.dtype == b.t.dtype
+        assert torch.equal(a.t.view(torch.uint8), b.t.view(torch.uint8)), "level %d gradient differs" % j
+        assert float(b.t.float().abs().max()) > 0
+    o0, o1 = out0.cpu().numpy(), out1.cpu().numpy()
+    assert np.allclose(o0[:6], o1[:6], rtol=2e-6, atol=0) and o0[6] == o1[6] and o0[7] == o1[7]
+    # ragged geometry is refused by the support test (the recorded step then keeps the chain)
+    odd = [ops.Act(torch.zeros(B, 25, 25, 32).cuda(), 19)] + levels[1:]
+    assert not losses.mse_train_supported(odd, torch.zeros(B, 18, 25, 25).cuda())
+    report("one-pass heat-map loss (%s, %dx%dx%d): 5 gradient tensors bit-identical to export -> loss -> import, losses %s vs %s"
+           % (str(dtype).split(".")[1], B, H, W, np.round(o1[:5], 6).tolist(), np.round(o0[:5], 6).tolist()))
