@@ -387,6 +387,13 @@ int mpn_nms(const float* dets, int64_t n, float thresh, int mode, int64_t* keep_
 int64_t mpn_nms_batched_workspace_bytes(int B, int64_t nmax);
 int mpn_nms_batched(const float* dets, int64_t dets_stride, const int32_t* counts, int B, int64_t nmax, float thresh, int mode,
                     int64_t* keep_out, int64_t keep_stride, int64_t* num_out, void* workspace, void* stream);
+/* mpn_nms_batched with a cap ahead of the suppression: per image only the top_k best-scored candidates (ties by index: the
+ * order of the sort) take part, the rest are dropped.  NOT in the reference (posenet.py:269-285 hands every candidate above
+ * 0.05 to nms) and off unless the caller asks: it bounds the N x N/64 mask of a dense image (A = 76 725 at 640x640: 736 MB)
+ * to top_k x top_k/64.  workspace: mpn_nms_batched_workspace_bytes(B, min(nmax, top_k)); keep_stride >= min(nmax, top_k). */
+int mpn_nms_batched_topk(const float* dets, int64_t dets_stride, const int32_t* counts, int B, int64_t nmax, int64_t top_k,
+                         float thresh, int mode, int64_t* keep_out, int64_t keep_stride, int64_t* num_out, void* workspace,
+                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer: torch.optim.Adam semantics (training/multipose_keypoint_train.py:106-110), fused over

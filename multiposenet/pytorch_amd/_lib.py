@@ -147,6 +147,7 @@ SIGNATURES = {
     "mpn_gather_dets_batched": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _vp, _i64, _vp]),
     "mpn_nms_batched_workspace_bytes": (_i64, [_i, _i64]),
     "mpn_nms_batched": (_i, [_vp, _i64, _vp, _i, _i64, _f, _i, _vp, _i64, _vp, _vp, _vp]),
+    "mpn_nms_batched_topk": (_i, [_vp, _i64, _vp, _i, _i64, _i64, _f, _i, _vp, _i64, _vp, _vp, _vp]),
     "mpn_nms_workspace_bytes": (_i64, [_i64]),
     "mpn_nms": (_i, [_vp, _i64, _f, _i, _vp, _vp, _vp, _vp]),
     "mpn_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _f, _vp]),

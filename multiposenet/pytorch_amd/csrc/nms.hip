@@ -96,13 +96,20 @@ struct NmsBatch {
     char* ws; long ws_stride;                    // per image: sorted [nmax*5 f32] | order [nmax i32] | remv [cb u64] | mask [nmax*cb u64]
     long off_order, off_remv, off_mask;
     int cb;                                      // mask words per row = ceil(nmax / 64)
+    int cap;                                     // 0, or: only the `cap` best-scored candidates of an image enter the suppression
 };
-__device__ __forceinline__ int nb_count(const NmsBatch& q, int b) { return q.counts ? q.counts[b] : q.n_host; }
+// candidates of image b / the ones that take part in the suppression (the best `cap` of them after the sort)
+__device__ __forceinline__ int nb_all(const NmsBatch& q, int b) { return q.counts ? q.counts[b] : q.n_host; }
+__device__ __forceinline__ int nb_count(const NmsBatch& q, int b) {
+    const int n = nb_all(q, b);
+    return (q.cap > 0 && n > q.cap) ? q.cap : n;
+}
 
 __global__ void nms_rank_kernel(const NmsBatch q) {
     __shared__ float ssc[1024];
     const int b = blockIdx.z;
-    const int n = nb_count(q, b);
+    const int n = nb_all(q, b);
+    const int live = nb_count(q, b);
     if ((int)(blockIdx.x * blockDim.x) >= n) return;
     const float* __restrict__ dets = q.dets + (long)b * q.dets_stride;
     float* __restrict__ sorted = reinterpret_cast<float*>(q.ws + (long)b * q.ws_stride);
@@ -120,7 +127,7 @@ __global__ void nms_rank_kernel(const NmsBatch q) {
         }
         __syncthreads();
     }
-    if (i < n) {
+    if (i < n && rank < live) {
         order[rank] = i;
         const float* s = dets + (long)i * 5;
         float* d = sorted + (long)rank * 5;
@@ -302,12 +309,14 @@ inline NmsLayout nms_layout(long nmax) {
     return l;
 }
 inline int launch_nms(const float* dets, long dets_stride, const int* counts, int n_host, int B, long nmax, float thresh, int mode,
-                      int64_t* keep_out, long keep_stride, int64_t* num_out, void* workspace, hipStream_t st) {
-    const NmsLayout l = nms_layout(nmax);
+                      int64_t* keep_out, long keep_stride, int64_t* num_out, void* workspace, hipStream_t st, long top_k = 0) {
+    const long nlive = (top_k > 0 && top_k < nmax) ? top_k : nmax;      // rows of the sorted / mask scratch
+    const NmsLayout l = nms_layout(nlive);
     NmsBatch q;
     q.dets = dets; q.dets_stride = dets_stride; q.counts = counts; q.n_host = n_host;
     q.ws = (char*)workspace; q.ws_stride = l.total;
     q.off_order = l.off_order; q.off_remv = l.off_remv; q.off_mask = l.off_mask; q.cb = l.cb;
+    q.cap = top_k > 0 ? (int)nlive : 0;
     const long tri = (long)l.cb * (l.cb + 1) / 2;
     if (tri > 0x7fffffffL) return MPN_E_UNSUPPORTED;
     hipLaunchKernelGGL(nms_rank_kernel, dim3((unsigned)((nmax + 255) / 256), 1, B), dim3(256), 0, st, q);
@@ -342,4 +351,18 @@ extern "C" int mpn_nms_batched(const float* dets, int64_t dets_stride, const int
     MPN_CHECK_ARG(nmax > 0 && nmax < (1 << 30) && keep_stride >= nmax && dets_stride >= nmax * 5);
     return launch_nms(dets, (long)dets_stride, counts, 0, B, (long)nmax, thresh, mode, keep_out, (long)keep_stride, num_out, workspace,
                       (hipStream_t)stream);
+}
+
+// mpn_nms_batched with a cap ahead of the suppression: per image only the top_k best-scored candidates (ties by index, the
+// order of the sort) take part; the rest are dropped as if they had not passed the score filter.  Not in the reference
+// (posenet.py:269-285 hands every candidate above 0.05 to nms), off unless asked for: it bounds the N x N/64 mask of a dense
+// image (A = 76 725 at 640x640: 736 MB) to top_k x top_k/64.  workspace: mpn_nms_batched_workspace_bytes(B, min(nmax, top_k)).
+extern "C" int mpn_nms_batched_topk(const float* dets, int64_t dets_stride, const int32_t* counts, int B, int64_t nmax, int64_t top_k,
+                                    float thresh, int mode, int64_t* keep_out, int64_t keep_stride, int64_t* num_out, void* workspace,
+                                    void* stream) {
+    MPN_CHECK_ARG(dets && counts && keep_out && num_out && workspace && B > 0 && (mode == 0 || mode == 1) && top_k > 0);
+    const int64_t nlive = top_k < nmax ? top_k : nmax;
+    MPN_CHECK_ARG(nmax > 0 && nmax < (1 << 30) && keep_stride >= nlive && dets_stride >= nmax * 5);
+    return launch_nms(dets, (long)dets_stride, counts, 0, B, (long)nmax, thresh, mode, keep_out, (long)keep_stride, num_out, workspace,
+                      (hipStream_t)stream, (long)top_k);
 }

@@ -5,14 +5,19 @@
     results = tester.infer_image_multiscale(img, 'name.jpg', image_id)    # body of Tester.coco_eval() for one image (:143-175):
                                                                 # 5 scales x {original, flipped} test-time augmentation
 
+    results = tester.coco_eval(images)                         # :131-191 from decoded images on: results file in COCO order
+    mean, std = tester.val()                                   # :515-543 validation-loss loop
+
 ``img`` is the decoded image the reference gets from ``cv2.imread(...).astype(np.float32)``: [H, W, 3] BGR, 0..255.  Decoding
-and the COCO tools (cv2.imread, pycocotools: tester.py:133-139,176-191) stay with the caller — neither library exists in
-this image.  Everything between the decoded image and the result dicts runs on the device: OpenCV-rule resizes
+and the COCO annotation tools (cv2.imread, pycocotools: tester.py:133-139,179-186) stay with the caller — neither library
+exists in this image; the result files (:176-178, :243-245) are written here.  Everything between the decoded image and the result dicts runs on the device: OpenCV-rule resizes
 (csrc/peaks.hip: mpn_resize), the network, heat-map averaging, peak extraction (network/joint_utils.py) and the PRN
 assignment (prn_process.py).  ``cv2.resize`` is restated, not linked: parity with OpenCV is unpinned (no cv2 here), see
 DESIGN.md.
 """
+import json
 import logging
+import os
 
 import numpy as np
 import torch
@@ -256,11 +261,45 @@ class Tester(object):
         return out
 
     def test(self, images):
-        """tester.py:194-245 over decoded images: ``images`` maps file name -> [H, W, 3] BGR array."""
+        """tester.py:194-245 over decoded images: ``images`` maps file name -> [H, W, 3] BGR array.  With
+        ``params.testresult_write_json`` the result list also goes to <testresult_dir>multipose_results.json (:243-245);
+        drawing the canvases (:238-241) needs cv2 and stays with the caller."""
         out = []
         for name, img in images.items():
             out.extend(self.infer_image(img, name))
+        if self.params.testresult_write_json:
+            with open(self.params.testresult_dir + 'multipose_results.json', "w") as f:
+                json.dump(out, f)
         return out
+
+    def coco_eval(self, images, coco=None):
+        """tester.py:131-191 from the decoded images on: ``images`` yields (image_id, file_name, [H, W, 3] BGR array) — what the
+        reference reads with pycocotools + cv2.imread.  Every image runs the 5-scale, flipped test-time augmentation; the results
+        (keypoints in COCO order) are written to ``params.coco_result_filename`` (indent 4, :176-178).  With pycocotools present
+        and ``coco`` the loaded annotation object, the keypoint evaluation runs as in :179-186 and the file is removed unless
+        ``params.testresult_write_json`` (:188-189); without it (this image has none) the file is the product and is kept.
+        Returns the result list."""
+        results, img_ids = [], []
+        for image_id, file_name, img in images:
+            img_ids.append(image_id)
+            results.extend(self.infer_image_multiscale(img, file_name, image_id))
+        ann_filename = self.params.coco_result_filename
+        with open(ann_filename, "w") as f:
+            json.dump(results, f, indent=4)
+        if coco is not None:
+            try:
+                from pycocotools.cocoeval import COCOeval
+            except ImportError:
+                logger.warning("pycocotools is not installed: results left in %s", ann_filename)
+                return results
+            ev = COCOeval(coco, coco.loadRes(ann_filename), 'keypoints')
+            ev.params.imgIds = img_ids
+            ev.evaluate()
+            ev.accumulate()
+            ev.summarize()
+            if not self.params.testresult_write_json:
+                os.remove(ann_filename)
+        return results
 
     # ------------------------------------------------------------------ multi-scale + flip (Tester.coco_eval, :143-175)
     def _get_multiplier(self, img):

@@ -324,9 +324,10 @@ class poseNet(nn.Module):
         [nms_scores, nms_class, boxes]]); entry b equals what the reference returns for image b run alone."""
         return self._entire_net(img_batch, all_images=True)
 
-    def forward_all_images_padded(self, img_batch):
+    def forward_all_images_padded(self, img_batch, pre_nms_top_n=None):
         """forward_all_images for batched post-processing: (heat-maps [B,18,H/4,W/4], boxes [B,nmax,4], scores [B,nmax], kept) with
-        image b's detections in rows [:kept[b]] (descending score; single class) — no per-image tensors or Python lists."""
+        image b's detections in rows [:kept[b]] (descending score; single class) — no per-image tensors or Python lists.
+        pre_nms_top_n: optional cap on the candidates that enter the suppression (ops.detect_batched; not in the reference)."""
         self._prepare(img_batch)
         eng = self._engine
         ctx = Ctx(False)
@@ -337,7 +338,8 @@ class poseNet(nn.Module):
         classification, regression = eng.detection_head(ctx, det)
         self._finish_forward(ctx)
         transformed_anchors = decode_and_clip(self.anchors(img_batch), regression, img_batch)
-        boxes, scores, kept = ops.detect_batched(transformed_anchors, classification.reshape(classification.shape[0], -1), 0.05, 0.5, padded=True)
+        boxes, scores, kept = ops.detect_batched(transformed_anchors, classification.reshape(classification.shape[0], -1), 0.05, 0.5, padded=True,
+                                                 pre_nms_top_n=pre_nms_top_n)
         return predict_keypoint, boxes, scores, kept
 
     def _entire_net(self, img_batch, all_images):

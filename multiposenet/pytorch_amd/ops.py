@@ -839,11 +839,13 @@ def gather_dets(dets, keep):
     return boxes, scores
 
 
-def detect_batched(boxes, scores, score_thresh, iou_thresh, mode=0, ws_limit=4 << 30, padded=False):
+def detect_batched(boxes, scores, score_thresh, iou_thresh, mode=0, ws_limit=4 << 30, padded=False, pre_nms_top_n=None):
     """Score filter + per-image NMS + gather for EVERY image of a batch with two host round trips per batch (the candidate
     counts size the NMS launches, the kept counts size the returned tensors) instead of two per image.
     boxes [B,A,4], scores [B,A] (f32, contiguous).  Returns per image (boxes[k,4], scores[k]) device tensors (views); with
-    padded=True the batch-wide tensors themselves: (boxes [B,nmax,4], scores [B,nmax] in descending order, kept counts list)."""
+    padded=True the batch-wide tensors themselves: (boxes [B,nmax,4], scores [B,nmax] in descending order, kept counts list).
+    pre_nms_top_n (not in the reference; None = every candidate, as posenet.py:269-285): only that many best-scored candidates of
+    an image enter the suppression, which bounds its N x N/64 mask."""
     B, A = scores.shape[0], scores.shape[1]
     dev = scores.device
     dets = torch.empty((B, A, 5), dtype=torch.float32, device=dev)
@@ -855,6 +857,10 @@ def detect_batched(boxes, scores, score_thresh, iou_thresh, mode=0, ws_limit=4 <
         if padded:
             return torch.zeros((B, 0, 4), dtype=torch.float32, device=dev), torch.zeros((B, 0), dtype=torch.float32, device=dev), [0] * B
         return [(None, None)] * B
+    ncand = nmax
+    top = int(pre_nms_top_n) if pre_nms_top_n else 0
+    if top > 0:
+        nmax = min(nmax, top)                          # rows of the sort / mask scratch and of the outputs
     keep = torch.empty((B, nmax), dtype=torch.int64, device=dev)
     num = torch.empty((B,), dtype=torch.int64, device=dev)
     per_img = call("mpn_nms_batched_workspace_bytes", 1, nmax)
@@ -862,9 +868,13 @@ def detect_batched(boxes, scores, score_thresh, iou_thresh, mode=0, ws_limit=4 <
     for b0 in range(0, B, group):
         nb = min(group, B - b0)
         ws = workspace(per_img * nb, dev, slot=4)
-        call("mpn_nms_batched", ctypes.c_void_p(dets.data_ptr() + b0 * A * 5 * 4), A * 5, ctypes.c_void_p(counts.data_ptr() + b0 * 4), nb, nmax,
-             float(iou_thresh), mode, ctypes.c_void_p(keep.data_ptr() + b0 * nmax * 8), nmax, ctypes.c_void_p(num.data_ptr() + b0 * 8),
-             ptr(ws), stream_ptr())
+        head = (ctypes.c_void_p(dets.data_ptr() + b0 * A * 5 * 4), A * 5, ctypes.c_void_p(counts.data_ptr() + b0 * 4), nb, ncand)
+        tail = (float(iou_thresh), mode, ctypes.c_void_p(keep.data_ptr() + b0 * nmax * 8), nmax, ctypes.c_void_p(num.data_ptr() + b0 * 8),
+                ptr(ws), stream_ptr())
+        if top > 0:
+            call("mpn_nms_batched_topk", *(head + (top,) + tail))
+        else:
+            call("mpn_nms_batched", *(head + tail))
     out_boxes = torch.empty((B, nmax, 4), dtype=torch.float32, device=dev)
     out_scores = torch.empty((B, nmax), dtype=torch.float32, device=dev)
     call("mpn_gather_dets_batched", ptr(dets), A * 5, ptr(keep), nmax, ptr(num), B, nmax, ptr(out_boxes), ptr(out_scores), nmax, stream_ptr())

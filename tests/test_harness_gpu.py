@@ -147,4 +147,17 @@ def test_tester_single_scale_and_multiscale_flip(tmp_path):
     assert rm == tester.infer_image_multiscale(img, "a.jpg", 5)
     for r in rm:
         assert len(r["keypoints"]) == 51
-    report("Tester: single-scale %d people, multi-scale+flip %d people on a random image (He weights)" % (len(r1), len(rm)))
+    # result files: coco_eval (tester.py:176-178, indent 4, COCO keypoint order) and test() (:243-245)
+    import json
+    params.coco_result_filename = str(tmp_path / "coco_results.json")
+    img2 = rs.uniform(0, 255, (80, 64, 3)).astype(np.float32)
+    got = tester.coco_eval([(5, "a.jpg", img), (9, "b.jpg", img2)])
+    assert got == rm + tester.infer_image_multiscale(img2, "b.jpg", 9)
+    with open(params.coco_result_filename) as f:
+        text = f.read()
+    assert json.loads(text) == got and (not got or text.startswith("[\n    {"))
+    params.testresult_write_json, params.testresult_dir = True, str(tmp_path) + "/"
+    single = tester.test({"a.jpg": img})
+    with open(str(tmp_path / "multipose_results.json")) as f:
+        assert json.load(f) == single == tester.infer_image(img, "a.jpg")
+    report("Tester: single-scale %d people, multi-scale+flip %d people on a random image (He weights); coco_eval / test result files" % (len(r1), len(rm)))

@@ -623,3 +623,56 @@ def test_one_pass_heatmap_loss_equals_the_export_loss_import_chain(dtype):
     assert not losses.mse_train_supported(odd, torch.zeros(B, 18, 25, 25).cuda())
     report("one-pass heat-map loss (%s, %dx%dx%d): 5 gradient tensors bit-identical to export -> loss -> import, losses %s vs %s"
            % (str(dtype).split(".")[1], B, H, W, np.round(o1[:5], 6).tolist(), np.round(o0[:5], 6).tolist()))
+
+
+def test_pre_nms_top_k_cap_equals_the_oracle_on_the_best_k_candidates():
+    """mpn_nms_batched_topk / ops.detect_batched(pre_nms_top_n=K): per image the result equals the oracle's NMS over the K
+    best-scored candidates (stable: score ties by index) and the plain call when an image has fewer than K; the scratch is
+    sized by K, not by the candidate count."""
+    from multiposenet.pytorch_amd import ops
+    from multiposenet.pytorch_amd._lib import call
+    from oracle import nms_oracle
+    rs = np.random.RandomState(5)
+    counts = [0, 1, 40, 100, 101, 900, 2500]
+    B, cap, K = len(counts), 2600, 100
+    dets = np.zeros((B, cap, 5), np.float32)
+    for b, n in enumerate(counts):
+        xy = rs.uniform(0, 300, (n, 2)); wh = rs.uniform(8, 150, (n, 2))
+        dets[b, :n] = np.concatenate([xy, xy + wh, np.round(rs.uniform(0.05, 1.0, (n, 1)), 2)], 1)      # rounded: many score ties
+    d = torch.from_numpy(dets).cuda()
+    cnt = torch.tensor(counts, dtype=torch.int32, device="cuda")
+    nmax = max(counts)
+    assert call("mpn_nms_batched_workspace_bytes", B, K) * 100 < call("mpn_nms_batched_workspace_bytes", B, nmax)
+    for mode, name in ((0, "gpu"), (1, "cpu")):
+        keep = torch.full((B, K), -1, dtype=torch.int64, device="cuda")
+        num = torch.full((B,), -1, dtype=torch.int64, device="cuda")
+        ws = torch.empty(call("mpn_nms_batched_workspace_bytes", B, K), dtype=torch.uint8, device="cuda")
+        call("mpn_nms_batched_topk", ops.ptr(d), cap * 5, ops.ptr(cnt), B, nmax, K, 0.5, mode, ops.ptr(keep), K, ops.ptr(num), ops.ptr(ws), ops.stream_ptr())
+        torch.cuda.synchronize()
+        for b, n in enumerate(counts):
+            got = keep[b, :int(num[b])].cpu().numpy()
+            if n == 0:
+                assert got.size == 0
+                continue
+            best = np.argsort(-dets[b, :n, 4], kind="stable")[:K]          # the sort's order: score descending, ties by index
+            want = best[nms_oracle.nms(dets[b, best], 0.5, name)]
+            assert np.array_equal(got, want), "image %d (n=%d, mode %s)" % (b, n, name)
+            if n <= K:
+                assert np.array_equal(got, nms_oracle.nms(dets[b, :n], 0.5, name))
+    # through detect_batched: boxes + scores, candidates in their own [B, A] layout
+    A = 3000
+    boxes = torch.zeros(B, A, 4, device="cuda"); scores = torch.zeros(B, A, device="cuda")
+    for b, n in enumerate(counts):
+        boxes[b, :n] = d[b, :n, :4]; scores[b, :n] = d[b, :n, 4]
+    ob, os_, kept = ops.detect_batched(boxes, scores, 0.04, 0.5, padded=True, pre_nms_top_n=K)
+    assert ob.shape[1] <= K
+    for b, n in enumerate(counts):
+        if n == 0:
+            assert kept[b] == 0
+            continue
+        best = np.argsort(-dets[b, :n, 4], kind="stable")[:K]
+        want = best[nms_oracle.nms(dets[b, best], 0.5, "gpu")]
+        assert kept[b] == len(want) and np.array_equal(ob[b, :kept[b]].cpu().numpy(), dets[b, want, :4])
+        assert np.array_equal(os_[b, :kept[b]].cpu().numpy(), dets[b, want, 4])
+    report("pre-NMS top-%d cap: %d images with %s candidates == oracle NMS over the best %d, both modes; scratch %d x smaller"
+           % (K, B, counts, K, call("mpn_nms_batched_workspace_bytes", B, nmax) // call("mpn_nms_batched_workspace_bytes", B, K)))
