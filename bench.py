@@ -238,6 +238,8 @@ def main():
         dist = None
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if use_dist else 0)
+    if os.environ.get("MPN_MAIN_PRIORITY"):         # scheduling experiment: the step's main stream as a prioritised HIP stream
+        torch.cuda.set_stream(torch.cuda.Stream(dev, priority=int(os.environ["MPN_MAIN_PRIORITY"])))
 
     from multiposenet.pytorch_amd import ddp, ops
     from multiposenet.pytorch_amd.network.posenet import poseNet

@@ -118,7 +118,7 @@ class Engine(object):
         if not self.overlap_wgrad or device.type != "cuda":
             return None
         if self._side is None:
-            self._side = torch.cuda.Stream(device=device)
+            self._side = torch.cuda.Stream(device=device, priority=int(os.environ.get("MPN_SIDE_PRIORITY", "0")))
         return self._side
 
     def _on_side(self, ctx, device, keep, fn, torch_ops=False):
