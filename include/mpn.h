@@ -93,8 +93,8 @@ typedef struct MpnConvParams {
      * the arrival order) and does the work of mpn_bn_finalize_train (stats: fin_out = [4][Cout] mean, invstd, scale, shift;
      * running statistics updated when fin_rm / fin_rv are given) or of mpn_bn_bwd_finalize (bnb_partial: fin_dgamma += ,
      * fin_dbeta += , fin_out = [3][Cout] k1, k2, k3 with fin_train selecting batch-statistics or frozen coefficients; mean /
-     * invstd are bnb_mean / bnb_invstd).  fin_counters: one zeroed uint32 per output-channel tile (>= 64 entries cover every
-     * shape); the launch leaves them zero again.  Launches sharing a counter array must be ordered (one stream).           */
+     * invstd are bnb_mean / bnb_invstd).  fin_counters: one zeroed uint32 per output-channel tile (64 entries; 64 + 32 * 128 with
+     * fin_group); the launch leaves them zero again.  Launches sharing a counter array must be ordered (one stream).           */
     /* Virtual channel concatenation of the gathered operand (kseg_n > 0; 3x3 / stride 1 / pad 1 launches with 16-bit operands):
      * the input is cat_s(nearest_upsample(kseg_x[s])) over kseg_n <= 4 segments of kseg_c channels each (Cin = kseg_n * kseg_c) —
      * torch.cat((up8(q5), up4(q4), up2(q3), q2), 1) feeding conv2 (network/posenet.py:311-315) — and is never materialised:
@@ -126,6 +126,13 @@ typedef struct MpnConvParams {
     double fin_count;
     float fin_momentum, fin_eps;
     int32_t fin_train;
+    /* Two-level in-launch finalize (fin_group = GS > 0, for launches of more than ~64 pixel tiles): the last workgroup of every
+     * group of GS consecutive pixel tiles sums the group's partial rows into one double-precision row of fin_gpart
+     * ([ceil(tiles / GS)][Cout][2] doubles, caller-owned scratch), the last GROUP to finish sums those and finalizes — no workgroup
+     * reads more than max(GS, tiles / GS) rows behind its acquire.  Needs ceil(tiles / GS) <= 128, at most 32 output-channel tiles
+     * and fin_counters of 64 + 32 * 128 zeroed entries.  Same results whatever the arrival order.                          */
+    int32_t fin_group;
+    double* fin_gpart;
 } MpnConvParams;
 #define MPN_MAX_SEG 5
 

@@ -45,6 +45,7 @@ class ConvParams(ctypes.Structure):
         ("fin_counters", ctypes.c_void_p), ("fin_gamma", ctypes.c_void_p), ("fin_beta", ctypes.c_void_p), ("fin_rm", ctypes.c_void_p),
         ("fin_rv", ctypes.c_void_p), ("fin_out", ctypes.c_void_p), ("fin_dgamma", ctypes.c_void_p), ("fin_dbeta", ctypes.c_void_p),
         ("fin_count", ctypes.c_double), ("fin_momentum", ctypes.c_float), ("fin_eps", ctypes.c_float), ("fin_train", ctypes.c_int32),
+        ("fin_group", ctypes.c_int32), ("fin_gpart", ctypes.c_void_p),
     ]
 
 

@@ -142,41 +142,83 @@ __device__ __forceinline__ void store_partial(float* dst, float a, float b, bool
 // In-launch finalize (mpn.h: fin_*).  Every workgroup of channel tile `tc` has published its partial pair per channel; the one that
 // draws the last ticket reduces the column [ntiles][TC] in a fixed order (SL interleaved slices per channel in double precision,
 // combined in slice order) — the same numbers whichever workgroup arrives last — and writes the BatchNorm coefficients.
+// With fin_group = GS > 0 the reduction has two levels, so that no single workgroup reads hundreds of rows behind an acquire (one
+// dependent round trip to memory per eight rows: 28 us at 225 tiles): the last arriver of every GROUP of GS consecutive pixel tiles
+// sums its group's rows and publishes a double-precision group row (while other groups are still computing), and the last group to
+// finish sums the <= 128 group rows.  Fixed orders on both levels: deterministic.
+constexpr int FIN_TOP_COUNTERS = 64;        // fin_counters[0 .. 64): one per channel tile; then [channel tile][FIN_MAX_GROUPS] group tickets
+constexpr int FIN_MAX_GROUPS = 128;
+constexpr int FIN_MAX_CTILES = 32;
+
+template <typename E2, int SL>
+__device__ __forceinline__ void fin_sum_rows(const E2* __restrict__ col, long stride, int r0, int r1, int sl, double& s1, double& s2) {
+    int r = r0 + sl;
+    for (; r + 7 * SL < r1; r += 8 * SL) {                     // eight loads in flight per thread
+        E2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = col[(long)(r + u * SL) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
+    }
+    for (; r < r1; r += SL) {
+        const E2 v = col[(long)r * stride];
+        s1 += (double)v.x; s2 += (double)v.y;
+    }
+}
+
+// true for the workgroup that drew ticket `last` of `counter` (which it leaves at zero again)
+__device__ __forceinline__ bool fin_ticket(unsigned* counter, unsigned last, volatile int* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its write-through stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = (old == last) ? 1 : 0;
+        if (old == last) {
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
 template <int TC>
-__device__ __forceinline__ void fin_last_arriver(const MpnConvParams& p, int c0, int tc, int ntiles, unsigned char* lds) {
+__device__ __forceinline__ void fin_last_arriver(const MpnConvParams& p, int c0, int tc, int tp, int ntiles, unsigned char* lds) {
     constexpr int SL = 256 / TC;                               // slices per channel (256 threads)
     volatile int* flag = reinterpret_cast<volatile int*>(lds + 12288);
     double* lds_d = reinterpret_cast<double*>(lds);            // [SL][TC][2]
     const int t = threadIdx.x;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its write-through stores
-    __syncthreads();
-    if (t == 0) {
-        const unsigned old = __hip_atomic_fetch_add(p.fin_counters + tc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = (old == (unsigned)(ntiles - 1)) ? 1 : 0;
-    }
-    __syncthreads();
-    if (*flag == 0) return;
-    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
     const float* __restrict__ part = p.stats ? p.stats : p.bnb_partial;
     const int cl = t % TC, sl = t / TC;
     const int c = c0 + cl;
+    const int GS = p.fin_group;
     double s1 = 0.0, s2 = 0.0;
-    if (c < p.Cout) {
-        const float* col = part + (long)c * 2;
-        const long stride = (long)p.Cout * 2;
-        int tile = sl;
-        for (; tile + 7 * SL < ntiles; tile += 8 * SL) {       // eight loads in flight per thread
-            float2 v[8];
+    if (GS > 0) {
+        const int g = tp / GS, ngroups = (ntiles + GS - 1) / GS;
+        const int r0 = g * GS, r1 = (r0 + GS < ntiles) ? r0 + GS : ntiles;
+        if (!fin_ticket(p.fin_counters + FIN_TOP_COUNTERS + tc * FIN_MAX_GROUPS + g, (unsigned)(r1 - r0 - 1), flag)) return;
+        if (c < p.Cout) fin_sum_rows<float2, SL>(reinterpret_cast<const float2*>(part) + c, (long)p.Cout, r0, r1, sl, s1, s2);
+        if (SL > 1) {
+            lds_d[(sl * TC + cl) * 2 + 0] = s1;
+            lds_d[(sl * TC + cl) * 2 + 1] = s2;
+            __syncthreads();
+            if (sl == 0) {
+                s1 = 0.0; s2 = 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2*>(col + (long)(tile + u * SL) * stride);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
+                for (int k = 0; k < SL; ++k) { s1 += lds_d[(k * TC + cl) * 2 + 0]; s2 += lds_d[(k * TC + cl) * 2 + 1]; }
+            }
         }
-        for (; tile < ntiles; tile += SL) {
-            const float2 v = *reinterpret_cast<const float2*>(col + (long)tile * stride);
-            s1 += (double)v.x; s2 += (double)v.y;
+        if (sl == 0 && c < p.Cout) {                            // the group's row, published like the tile rows
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.fin_gpart + ((long)g * p.Cout + c) * 2);
+            __hip_atomic_store(dst, (unsigned long long)__double_as_longlong(s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 1, (unsigned long long)__double_as_longlong(s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (!fin_ticket(p.fin_counters + tc, (unsigned)(ngroups - 1), flag)) return;
+        s1 = 0.0; s2 = 0.0;
+        if (c < p.Cout) fin_sum_rows<double2, SL>(reinterpret_cast<const double2*>(p.fin_gpart) + c, (long)p.Cout, 0, ngroups, sl, s1, s2);
+    } else {
+        if (!fin_ticket(p.fin_counters + tc, (unsigned)(ntiles - 1), flag)) return;
+        if (c < p.Cout) fin_sum_rows<float2, SL>(reinterpret_cast<const float2*>(part) + c, (long)p.Cout, 0, ntiles, sl, s1, s2);
     }
     if (SL > 1) {
         lds_d[(sl * TC + cl) * 2 + 0] = s1;
@@ -216,7 +258,6 @@ __device__ __forceinline__ void fin_last_arriver(const MpnConvParams& p, int c0,
             }
         }
     }
-    if (t == 0) __hip_atomic_store(p.fin_counters + tc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Epilogue.  Phase A (accumulator layout: lane = 4 consecutive couts of one pixel): scale, bias, residual,
@@ -525,7 +566,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
             store_partial(pk.bnb_partial + ((long)tp * p.Cout + c0 + t) * 2, a1, a2, pk.fin_counters != nullptr);
         }
     }
-    if (pk.fin_counters) fin_last_arriver<TC>(pk, c0, tc, ntiles, lds);
+    if (pk.fin_counters) fin_last_arriver<TC>(pk, c0, tc, tp, ntiles, lds);
 }
 
 // LDS-DMA plumbing (see conv_wgrad.hip for the probe-verified semantics): `buffer_load_dwordx4 ... lds` writes
@@ -1051,6 +1092,11 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     MPN_CHECK_ARG(!((p.res_mode || p.accumulate) && p.act && p.act != 3));
     MPN_CHECK_ARG(!p.fin_counters || (((p.stats != nullptr) != (p.bnb_partial != nullptr)) && p.fin_count > 0 && !p.nseg &&
                                       (p.stats ? p.fin_out != nullptr : true)));
+    if (p.fin_counters && p.fin_group) {                       // two-level finalize: group / channel-tile ticket ranges (mpn.h)
+        const long tiles = ((long)p.B * p.Ho * p.Wo + kTP - 1) / kTP;
+        MPN_CHECK_ARG(p.fin_group > 0 && p.fin_gpart && (tiles + p.fin_group - 1) / p.fin_group <= FIN_MAX_GROUPS &&
+                      (p.Cout_store + pick_tc(p, tiles) - 1) / pick_tc(p, tiles) <= FIN_MAX_CTILES);
+    }
     MPN_CHECK_ARG(!p.bnb_partial || (p.bnb_y && p.bnb_mean && p.bnb_invstd && !p.out_f32 && !p.nseg && !p.stats && !p.act &&
                                      (!p.bnb_relu || p.bnb_z || p.bnb_mask || (p.bnb_scale && p.bnb_shift)) &&
                                      (!p.bnb_mask || (p.y_sB == (int64_t)p.Ho * p.Wo * p.y_sP && p.y_sP == p.Cout_store))));

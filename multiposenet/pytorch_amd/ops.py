@@ -471,12 +471,12 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         tiles = call("mpn_conv_stats_tiles", ctypes.byref(p))
         stats = torch.empty((tiles, Cout, 2), dtype=torch.float32, device=dev)
         p.stats = stats.data_ptr()
-        if bn_fin is not None and tiles <= FIN_MAX_TILES and not call("mpn_conv_pw_selected", ctypes.byref(p)):
+        if bn_fin is not None and fin_plan(tiles) is not None and not call("mpn_conv_pw_selected", ctypes.byref(p)):
             # the last workgroup of every channel tile turns the tile partials into the BatchNorm coefficients (no finalize launch):
             # the BNState comes back in the stats slot
             gamma, beta, rm, rv, momentum, eps = bn_fin
             keep, stats = stats, BNState(Cout, dev)
-            p.fin_counters = fin_counters(dev).data_ptr()
+            fin_attach(p, tiles, Cout, dev)
             p.fin_gamma, p.fin_beta = gamma.data_ptr(), beta.data_ptr()
             p.fin_rm = rm.data_ptr() if rm is not None else None
             p.fin_rv = rv.data_ptr() if rv is not None else None
@@ -496,12 +496,12 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         p.bnb_mean, p.bnb_invstd = st.mean.data_ptr(), st.invstd.data_ptr()
         p.bnb_scale, p.bnb_shift = st.scale.data_ptr(), st.shift.data_ptr()
         p.bnb_relu = 1 if relu else 0
-        if len(bnb) > 4 and bnb[4] is not None and tiles <= FIN_MAX_TILES and not call("mpn_conv_pw_selected", ctypes.byref(p)):
+        if len(bnb) > 4 and bnb[4] is not None and fin_plan(tiles) is not None and not call("mpn_conv_pw_selected", ctypes.byref(p)):
             # ... and the last workgroup of every channel tile finishes the reduction: dgamma / dbeta and the (k1, k2, k3) of
             # dy = k1*g + k2*y + k3 (mpn_bn_bwd_finalize's work); the coefficient tensor comes back in the stats slot
             gamma, train, dgamma, dbeta = bnb[4]
             keep, stats = stats, (torch.empty((3, Cout), dtype=torch.float32, device=dev) if train else None)
-            p.fin_counters = fin_counters(dev).data_ptr()
+            fin_attach(p, tiles, Cout, dev)
             p.fin_gamma = gamma.data_ptr()
             p.fin_out = stats.data_ptr() if stats is not None else None
             p.fin_dgamma = dgamma.data_ptr() if dgamma is not None else None
@@ -620,8 +620,35 @@ cast_bf16 = cast_lowp
 
 
 _fin_counters = {}
-# one workgroup per channel tile does the reduction: beyond this many pixel tiles the separate (wide) finalize launch is faster
+# In-launch BatchNorm finalize (mpn.h: fin_*).  Up to FIN_MAX_TILES pixel tiles one workgroup per channel tile does the whole
+# reduction; beyond that a single reader behind an acquire is slower than the separate (wide) finalize launch.  The two-level form
+# (groups of ~sqrt(tiles) pixel tiles, mpn.h: fin_group) up to FIN_GROUP_MAX_TILES tiles is built and tested but OFF: dropping the
+# 95 forward finalize launches of a step from the recorded list measures 1.6 ms (tools/ablate_launches.py), yet every workgroup of
+# a finalizing launch has to drain its stores before it draws a ticket, and that costs more than the launches did
+# (37.85 -> 38.11 ms/step, profiles/r03_bn_finalize_two_level_ab.txt).
 FIN_MAX_TILES = int(os.environ.get("MPN_BN_FIN_MAX_TILES", "64"))
+FIN_GROUP_MAX_TILES = int(os.environ.get("MPN_BN_FIN_GROUP_MAX_TILES", "0"))
+FIN_MAX_GROUPS, FIN_COUNTERS = 128, 64 + 32 * 128
+
+
+def fin_plan(tiles):
+    """None: separate finalize launch; 0: one-level in-launch finalize; GS > 0: two levels with groups of GS pixel tiles."""
+    if tiles <= FIN_MAX_TILES:
+        return 0
+    if tiles > FIN_GROUP_MAX_TILES:
+        return None
+    gs = 16
+    while gs * gs < tiles:
+        gs *= 2
+    return gs if (tiles + gs - 1) // gs <= FIN_MAX_GROUPS else None
+
+
+def fin_attach(p, tiles, Cout, device):
+    p.fin_counters = fin_counters(device).data_ptr()
+    gs = fin_plan(tiles)
+    if gs:
+        p.fin_group = gs
+        p.fin_gpart = workspace(((tiles + gs - 1) // gs) * Cout * 16, device, slot=8).data_ptr()
 
 
 def fin_counters(device):
@@ -631,7 +658,7 @@ def fin_counters(device):
     key = (device, stream_handle() if device.type == "cuda" else 0)
     t = _fin_counters.get(key)
     if t is None:
-        t = _fin_counters[key] = torch.zeros(256, dtype=torch.int32, device=device)
+        t = _fin_counters[key] = torch.zeros(FIN_COUNTERS, dtype=torch.int32, device=device)
     return t
 
 
