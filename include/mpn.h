@@ -251,6 +251,17 @@ int mpn_bn_finalize_eval(int C, const float* gamma, const float* beta, const flo
  * what the backward of relu(bn(.) + shortcut) (network/fpn.py:30-33) needs of z, at 1/16 of its bytes. */
 int mpn_bn_act_forward(const void* y, const void* res, void* z, const float* scale, const float* shift,
                        int64_t P, int C, int Cs, int relu, int dtype, uint8_t* mask, void* stream);
+/* mpn_bn_finalize_train + mpn_bn_act_forward in ONE launch (training forward: z = act(bn(y) [+ res]) with batch statistics from the
+ * conv epilogue's tile partials `stats` [tiles][C][2]; count = P).  The first ceil(C / 4) workgroups of the grid finalize four
+ * channels each — the arithmetic of mpn_bn_finalize_train, same results — publish mean / invstd / scale / shift and bump *flag; all
+ * workgroups wait for *flag to reach that count before they read the coefficients.  *flag MUST be zero at launch and is left at
+ * ceil(C / 4): the caller zeroes its flag words once per forward pass (one word per BatchNorm layer).  Returns
+ * MPN_E_UNSUPPORTED when the tensor is too small for the grid to contain the finalizing workgroups (use the two launches). */
+int mpn_bn_act_finalize_supported(int64_t P, int C, int Cs, int dtype);      /* 1 when the launch below can be used */
+int mpn_bn_act_finalize_forward(const void* y, const void* res, void* z, int64_t P, int C, int Cs, int relu, int dtype, uint8_t* mask,
+                                const float* stats, int tiles, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                                float* shift, uint32_t* flag, void* stream);
 /* backward, stage 1: g = dz * (z > 0 if relu); partial sums of g and g*xhat per channel.
  * With relu and z == NULL the mask is recomputed as (y*mask_scale + mask_shift) > 0 — the forward's own expression
  * (valid when the forward had no residual input), which saves reading z. */

@@ -39,6 +39,8 @@ class Ctx(object):
         self.bnb = {}            # id(BN output Act) -> per-tile backward statistics produced by the launch that completed its gradient
         self.side_deferred = []  # side-stream closures held back for later fork points (Engine.side_defer)
         self.side_count = 0
+        self.fin_flags = None    # zeroed flag words of the fused finalize + bn_act launches of this pass (Engine._fin_flag)
+        self.fin_flag_next = 0
         self.lazy_res = {}       # id(Act) -> (dz, mask bits): shortcut gradient dz * (z > 0) NOT materialised; the convolution whose
                                  # input gradient completes that Act adds it in its epilogue (Engine.defer_shortcut_grad)
 
@@ -94,6 +96,9 @@ class Engine(object):
         self.fold_bn = os.environ.get("MPN_FOLD_BN", "1") != "0"
         # the BatchNorm finalize steps (tile partials -> coefficients) run inside the producing conv launch (last-arriving workgroup)
         self.fuse_bn_finalize = os.environ.get("MPN_BN_FUSED_FINALIZE", "1") != "0"
+        # training forward: the finalize of layers too large for the in-launch form rides in the first blocks of the bn_act launch.
+        # Bit-identical and measured no faster (the chip-wide wait costs what the kernel boundary saved): off
+        self.fuse_bn_act_finalize = os.environ.get("MPN_BN_ACT_FINALIZE", "0") == "1"
         # relu(bn3(.) + shortcut): the forward also writes the sign bits of z (1/16 of its bytes); both backward passes that need
         # the ReLU mask (statistics in the dgrad epilogue, bn_bwd_apply) read those instead of z
         self.bn_mask_bits = os.environ.get("MPN_BN_MASK_BITS", "1") != "0"
@@ -462,18 +467,40 @@ class Engine(object):
             for g in gs:
                 g.premasked = bool(mask_here)
 
+    def _fin_flag(self, ctx, device):
+        """One zeroed uint32 word per fused finalize + bn_act launch of this pass (mpn.h: mpn_bn_act_finalize_forward): a block of
+        words zeroed by ONE fill launch when the pass first needs it (recorded steps re-zero it on every replay)."""
+        if ctx.fin_flags is None or ctx.fin_flag_next >= ctx.fin_flags.numel():
+            ctx.fin_flags = torch.empty(512, dtype=torch.float32, device=device)       # 0.0f == the all-zero word
+            call("mpn_fill_f32", ops.ptr(ctx.fin_flags), 0.0, ctx.fin_flags.numel(), ops.stream_ptr())
+            ctx.fin_flag_next = 0
+            ctx.keep.append(ctx.fin_flags)
+        ctx.fin_flag_next += 1
+        return ctx.fin_flags.data_ptr() + 4 * (ctx.fin_flag_next - 1)
+
     def bn(self, ctx, y, stats, layer, relu, res=None, tag=""):
         train_stats = layer.training
+        want_mask = bool(self.bn_mask_bits and ctx.train and relu and res is not None)
+        z = None
         if train_stats:
+            momentum = layer.momentum if layer.momentum is not None else 0.1
             if isinstance(stats, ops.BNState):         # the conv launch finalized in place
                 st = stats
             else:
-                st = ops.bn_finalize_train(stats, y.P, layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var,
-                                           layer.momentum if layer.momentum is not None else 0.1, layer.eps)
+                fused = None
+                if self.fuse_bn_act_finalize:          # finalize inside the bn_act launch: one kernel boundary less in the forward chain
+                    fused = ops.bn_act_finalize(y, stats, layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var,
+                                                momentum, layer.eps, relu, self._fin_flag(ctx, y.t.device), res=res, tag=tag, want_mask=want_mask)
+                if fused is not None:
+                    z, st = fused
+                else:
+                    st = ops.bn_finalize_train(stats, y.P, layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var,
+                                               momentum, layer.eps)
             ctx.bn_train_ran = True
         else:
             st = ops.bn_finalize_eval(layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var, layer.eps)
-        z = ops.bn_act(y, st, relu, res=res, tag=tag, want_mask=bool(self.bn_mask_bits and ctx.train and relu and res is not None))
+        if z is None:
+            z = ops.bn_act(y, st, relu, res=res, tag=tag, want_mask=want_mask)
         if ctx.train:
             z.needs_grad = bool(y.needs_grad or layer.weight.requires_grad or layer.bias.requires_grad
                                 or (res is not None and res.needs_grad))

@@ -697,6 +697,22 @@ def bn_act(y, st, relu, res=None, needs_grad=False, tag="", want_mask=False):
     return z
 
 
+def bn_act_finalize(y, stats, gamma, beta, rm, rv, momentum, eps, relu, flag, res=None, needs_grad=False, tag="", want_mask=False):
+    """bn_finalize_train + bn_act in one launch (mpn.h: mpn_bn_act_finalize_forward).  flag: a zeroed uint32 word (data pointer) that
+    no other launch uses until it is zeroed again.  Returns (z, BNState), or None when the tensor is too small for the fused launch."""
+    dc = dtype_code(y.t.dtype)
+    if not call("mpn_bn_act_finalize_supported", y.P, y.C, y.Cs, dc):
+        return None
+    st = BNState(y.C, y.t.device)
+    z = Act(torch.empty_like(y.t), y.C, needs_grad, tag)
+    if want_mask and relu:
+        z.mask = torch.empty((y.P, y.Cs // (4 if y.t.dtype == torch.float32 else 8)), dtype=torch.uint8, device=y.t.device)
+    call("mpn_bn_act_finalize_forward", ptr(y.t), ptr(res.t) if res is not None else None, ptr(z.t), y.P, y.C, y.Cs, 1 if relu else 0, dc,
+         ptr(z.mask), ptr(stats), stats.shape[0], ptr(gamma), ptr(beta), ptr(rm), ptr(rv), momentum, eps,
+         ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ctypes.c_void_p(flag), stream_ptr())
+    return z, st
+
+
 def masked_copy(dz, mask_bits, out):
     """out = dz * mask (mask bits in bn_act's layout): the shortcut gradient of relu(bn(.) + shortcut), materialised."""
     call("mpn_bn_bwd_apply", ptr(dz.t), None, None, None, None, None, None, None, None, ptr(out.t), 0, dz.P, dz.C, dz.Cs, 1,

@@ -676,3 +676,55 @@ def test_pre_nms_top_k_cap_equals_the_oracle_on_the_best_k_candidates():
         assert np.array_equal(os_[b, :kept[b]].cpu().numpy(), dets[b, want, 4])
     report("pre-NMS top-%d cap: %d images with %s candidates == oracle NMS over the best %d, both modes; scratch %d x smaller"
            % (K, B, counts, K, call("mpn_nms_batched_workspace_bytes", B, nmax) // call("mpn_nms_batched_workspace_bytes", B, K)))
+
+
+@pytest.mark.parametrize("dtype,size", [(torch.bfloat16, 480), (torch.float32, 384)])
+def test_bn_finalize_inside_the_bn_act_launch_is_bit_identical(dtype, size):
+    """mpn_bn_act_finalize_forward: the first ceil(C/4) blocks of the bn_act grid finalize the batch statistics (the arithmetic of
+    mpn_bn_finalize_train), the rest wait on a flag word.  Same training step with the fused launch on and off: loss, gradient arena
+    and running statistics bit-identical; the separate finalize launches of the forward pass are gone; tensors too small for the
+    grid to hold the finalizing blocks fall back to the two launches."""
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    from multiposenet.pytorch_amd import _lib, ops
+    import multiposenet.pytorch_amd.ops as ops_mod
+    from test_round2_gpu import _train_setup
+    m, inputs, gts = _train_setup(50, dtype, 2, size, seed=171)
+    orig = _lib.call
+    calls = []
+
+    def counting(name, *a):
+        if name in calls[-1]:
+            calls[-1][name] += 1
+        return orig(name, *a)
+    ops_mod.call = counting
+    res = []
+    bn0 = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
+    try:
+        for fused in (False, True):
+            calls.append({"mpn_bn_finalize_train": 0, "mpn_bn_act_finalize_forward": 0, "mpn_bn_act_forward": 0})
+            m._engine.fuse_bn_act_finalize = fused
+            m.load_state_dict(bn0, strict=False)
+            m._arena.ensure_grads()
+            m._arena.grad_flat.zero_()
+            pred, saved = m(*inputs)
+            loss, log = poseNet.build_loss(saved, *gts)
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((loss.detach().clone(), m._arena.grad_flat.clone(),
+                        {k: v.clone() for k, v in m.state_dict().items() if "running_" in k}))
+    finally:
+        ops_mod.call = orig
+        m._engine.fuse_bn_act_finalize = False
+    (l0, g0, r0), (l1, g1, r1) = res
+    assert torch.equal(l0, l1) and torch.equal(g0, g1), "fused finalize + bn_act changed the step"
+    assert all(torch.equal(r0[k], r1[k]) for k in r0)
+    assert calls[0]["mpn_bn_act_finalize_forward"] == 0 and calls[1]["mpn_bn_act_finalize_forward"] > 10
+    assert calls[1]["mpn_bn_finalize_train"] < calls[0]["mpn_bn_finalize_train"]
+    assert calls[1]["mpn_bn_finalize_train"] + calls[1]["mpn_bn_act_finalize_forward"] == calls[0]["mpn_bn_finalize_train"]
+    # a tensor whose bn_act grid is smaller than ceil(C/4) blocks is refused
+    tiny = ops.Act(torch.zeros(1, 2, 2, 2048, device="cuda", dtype=dtype), 2048)
+    assert ops.bn_act_finalize(tiny, torch.zeros(1, 2048, 2, device="cuda"), torch.ones(2048, device="cuda"), torch.zeros(2048, device="cuda"),
+                               None, None, 0.1, 1e-5, True, torch.zeros(1, dtype=torch.int32, device="cuda").data_ptr()) is None
+    report("finalize inside bn_act (%s, R50 %dx%d B=2): %d separate finalize launches -> %d (+ %d fused), step bit-identical"
+           % (str(dtype).split(".")[1], size, size, calls[0]["mpn_bn_finalize_train"], calls[1]["mpn_bn_finalize_train"],
+              calls[1]["mpn_bn_act_finalize_forward"]))
