@@ -238,3 +238,31 @@ def test_trainer_under_two_ranks_writes_once_and_decides_together(tmp_path):
     assert [b.split("_")[1] for b in best] == ["1", "3"] and best[0].startswith("ckpt_1_0.75") and best[1].startswith("ckpt_3_0.25"), best
     assert [f for f in files if f.endswith(".h5")] == ["ckpt_2.h5", "ckpt_3.h5"] and [f for f in files if f.endswith(".pk")] == ["ckpt_3.h5.optimizer_state.pk"]
     assert res[0]["lr"] == [0.005] and res[0]["last_epoch"] == 3          # halved once, after epoch 2, on both ranks
+
+
+def test_host_plans_of_the_round3_launch_options():
+    """Host-side decisions that pick kernels: the in-launch BatchNorm finalize plan (one level up to 64 pixel tiles, two levels with
+    groups of ~sqrt(tiles) only when enabled, never more than 128 groups) and the geometry test of the one-pass heat-map loss."""
+    import torch
+    from multiposenet.pytorch_amd import ops
+    from multiposenet.pytorch_amd.network import losses
+    saved = ops.FIN_GROUP_MAX_TILES
+    try:
+        ops.FIN_GROUP_MAX_TILES = 0
+        assert ops.fin_plan(1) == 0 and ops.fin_plan(64) == 0 and ops.fin_plan(65) is None and ops.fin_plan(225) is None
+        ops.FIN_GROUP_MAX_TILES = 16384
+        assert [ops.fin_plan(t) for t in (65, 225, 256, 257, 900, 3600, 14400)] == [16, 16, 16, 32, 32, 64, 128]
+        assert ops.fin_plan(16385) is None
+        for t in (65, 225, 900, 3600, 14400):
+            gs = ops.fin_plan(t)
+            assert (t + gs - 1) // gs <= ops.FIN_MAX_GROUPS
+    finally:
+        ops.FIN_GROUP_MAX_TILES = saved
+    B, H, W = 2, 24, 40
+    lv = [ops.Act(torch.zeros(B, H >> s, W >> s, 32), c) for s, c in ((0, 19), (1, 19), (2, 19), (3, 19), (0, 18))]
+    heat = torch.zeros(B, 18, H, W)
+    assert losses.mse_train_supported(lv, heat)
+    assert not losses.mse_train_supported(lv, heat.permute(0, 1, 3, 2))                      # targets must be dense NCHW
+    assert not losses.mse_train_supported(lv[:1] + [ops.Act(torch.zeros(B, 13, 20, 32), 19)] + lv[2:], heat)    # a level off the power-of-two grid
+    assert not losses.mse_train_supported([ops.Act(a.t.half(), a.C) for a in lv], heat)      # internal predictions are f32
+    assert not losses.mse_train_supported(lv, torch.zeros(B, 18, 20, 40))                    # sides must be multiples of 8
