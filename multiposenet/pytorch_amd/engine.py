@@ -39,6 +39,7 @@ class Ctx(object):
         self.bnb = {}            # id(BN output Act) -> per-tile backward statistics produced by the launch that completed its gradient
         self.side_deferred = []  # side-stream closures held back for later fork points (Engine.side_defer)
         self.side_count = 0
+        self.fwd_side_join = False   # forward work is in flight on the side stream (Engine.det_pyramid): join before it is consumed
         self.fin_flags = None    # zeroed flag words of the fused finalize + bn_act launches of this pass (Engine._fin_flag)
         self.fin_flag_next = 0
         self.lazy_res = {}       # id(Act) -> (dz, mask bits): shortcut gradient dz * (z > 0) NOT materialised; the convolution whose
@@ -96,6 +97,8 @@ class Engine(object):
         self.fold_bn = os.environ.get("MPN_FOLD_BN", "1") != "0"
         # the BatchNorm finalize steps (tile partials -> coefficients) run inside the producing conv launch (last-arriving workgroup)
         self.fuse_bn_finalize = os.environ.get("MPN_BN_FUSED_FINALIZE", "1") != "0"
+        # forward: the two tiny-grid stride-2 convolutions of the detection pyramid (P6, P7) run on the side stream
+        self.p67_on_side = os.environ.get("MPN_P67_SIDE", "1") != "0"
         # training forward: the finalize of layers too large for the in-launch form rides in the first blocks of the bn_act launch.
         # Bit-identical and measured no faster (the chip-wide wait costs what the kernel boundary saved): off
         self.fuse_bn_act_finalize = os.environ.get("MPN_BN_ACT_FINALIZE", "0") == "1"
@@ -807,8 +810,23 @@ class Engine(object):
     def det_pyramid(self, ctx, c3, c4, c5):
         """fpn.py:107-114 (p4 is built from the UN-smoothed p5)."""
         f = self.m.fpn
-        p6, _ = self.conv(ctx, c5, f.conv6)
-        p7, _ = self.conv(ctx, self.relu(ctx, p6), f.conv7)
+        if self.p67_on_side and self.side_defer == 0 and self.side_stream(c5.t.device) is not None:
+            # P6 / P7 (3x3 stride 2 on 15x15 / 8x8 maps: 32 - 64 workgroups walking 576 / 72 k-steps, 190 + 31 us with the GPU
+            # nearly empty) go to the side stream and run under the rest of this pyramid and the keypoint head; the detection head
+            # joins (join_forward_side).  The holder keeps every tensor of the branch alive until then.
+            holder = {}
+
+            def branch():
+                holder["p6"], _ = self.conv(ctx, c5, f.conv6)
+                holder["r6"] = self.relu(ctx, holder["p6"])
+                holder["p7"], _ = self.conv(ctx, holder["r6"], f.conv7)
+            self._on_side(ctx, c5.t.device, (c5, holder), branch)
+            self.flush_side(ctx, c5.t.device)
+            ctx.fwd_side_join = True
+            p6, p7 = holder["p6"], holder["p7"]
+        else:
+            p6, _ = self.conv(ctx, c5, f.conv6)
+            p7, _ = self.conv(ctx, self.relu(ctx, p6), f.conv7)
         p5, _ = self.conv(ctx, c5, f.latlayer1)
         p4, _ = self.conv(ctx, c4, f.latlayer2, res=p5, res_mode=2)
         p3, _ = self.conv(ctx, c3, f.latlayer3, res=p4, res_mode=2)
@@ -853,8 +871,15 @@ class Engine(object):
         pred = self.export_internal(ctx, pr, "pred") if internal else self.export(ctx, pr, 18, Ho, Wo, "pred")
         return pred, saved
 
+    def join_forward_side(self, ctx, device):
+        """The main stream waits for forward work that was forked to the side stream (det_pyramid's P6 / P7 branch)."""
+        if ctx.fwd_side_join:
+            gpu_op(torch.cuda.current_stream(device).wait_stream, self.side_stream(device))
+            ctx.fwd_side_join = False
+
     def detection_head(self, ctx, feats):
         """posenet.py:327-328: shared towers over p3..p7, outputs written straight into [B,A,4] / [B,A,1]."""
+        self.join_forward_side(ctx, feats[0].t.device)
         m = self.m
         B = feats[0].B
         dev = feats[0].t.device
