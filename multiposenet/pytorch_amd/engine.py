@@ -97,8 +97,8 @@ class Engine(object):
         self.fold_bn = os.environ.get("MPN_FOLD_BN", "1") != "0"
         # the BatchNorm finalize steps (tile partials -> coefficients) run inside the producing conv launch (last-arriving workgroup)
         self.fuse_bn_finalize = os.environ.get("MPN_BN_FUSED_FINALIZE", "1") != "0"
-        # forward: the two tiny-grid stride-2 convolutions of the detection pyramid (P6, P7) run on the side stream
-        self.p67_on_side = os.environ.get("MPN_P67_SIDE", "1") != "0"
+        # forward: the detection pyramid runs on the side stream (0 = off, 1 = only its two tiny-grid stride-2 convolutions P6 / P7)
+        self.det_pyramid_side = int(os.environ.get("MPN_DET_PYRAMID_SIDE", "2"))
         # training forward: the finalize of layers too large for the in-launch form rides in the first blocks of the bn_act launch.
         # Bit-identical and measured no faster (the chip-wide wait costs what the kernel boundary saved): off
         self.fuse_bn_act_finalize = os.environ.get("MPN_BN_ACT_FINALIZE", "0") == "1"
@@ -810,30 +810,37 @@ class Engine(object):
     def det_pyramid(self, ctx, c3, c4, c5):
         """fpn.py:107-114 (p4 is built from the UN-smoothed p5)."""
         f = self.m.fpn
-        if self.p67_on_side and self.side_defer == 0 and self.side_stream(c5.t.device) is not None:
-            # P6 / P7 (3x3 stride 2 on 15x15 / 8x8 maps: 32 - 64 workgroups walking 576 / 72 k-steps, 190 + 31 us with the GPU
-            # nearly empty) go to the side stream and run under the rest of this pyramid and the keypoint head; the detection head
-            # joins (join_forward_side).  The holder keeps every tensor of the branch alive until then.
-            holder = {}
 
-            def branch():
-                holder["p6"], _ = self.conv(ctx, c5, f.conv6)
-                holder["r6"] = self.relu(ctx, holder["p6"])
-                holder["p7"], _ = self.conv(ctx, holder["r6"], f.conv7)
-            self._on_side(ctx, c5.t.device, (c5, holder), branch)
-            self.flush_side(ctx, c5.t.device)
+        def coarse(h):                                           # P6 / P7: 3x3 stride 2 on the 15x15 / 8x8 maps
+            h["p6"], _ = self.conv(ctx, c5, f.conv6)
+            h["r6"] = self.relu(ctx, h["p6"])
+            h["p7"], _ = self.conv(ctx, h["r6"], f.conv7)
+
+        def rest(h):
+            h["p5"], _ = self.conv(ctx, c5, f.latlayer1)
+            h["p4"], _ = self.conv(ctx, c4, f.latlayer2, res=h["p5"], res_mode=2)
+            h["p3"], _ = self.conv(ctx, c3, f.latlayer3, res=h["p4"], res_mode=2)
+            h["p5s"], _ = self.conv(ctx, h["p5"], f.toplayer0)
+            h["p4s"], _ = self.conv(ctx, h["p4"], f.toplayer1)
+            h["p3s"], _ = self.conv(ctx, h["p3"], f.toplayer2)
+        h = {}
+        dev = c5.t.device
+        mode = self.det_pyramid_side if (self.side_defer == 0 and self.side_stream(dev) is not None) else 0
+        if mode:
+            # Forward fork: this pyramid feeds only the detection head, which runs after the keypoint head — so it runs on the side
+            # stream under the keypoint head's launches and the detection head joins (join_forward_side).  P6 / P7 alone are 32 - 64
+            # workgroups walking 576 / 72 k-steps (190 + 31 us on a nearly empty chip): mode 1 moves just those (-0.13 ms/step),
+            # mode 2 the whole pyramid (another -0.06; profiles/r03_forward_side_fork_ab.txt).  `h` keeps every tensor of the branch
+            # alive until the join; the tape order (hence the backward pass) is the same as without the fork.
+            self._on_side(ctx, dev, (c3, c4, c5, h), (lambda: (coarse(h), rest(h))) if mode == 2 else (lambda: coarse(h)))
+            self.flush_side(ctx, dev)
             ctx.fwd_side_join = True
-            p6, p7 = holder["p6"], holder["p7"]
+            if mode != 2:
+                rest(h)
         else:
-            p6, _ = self.conv(ctx, c5, f.conv6)
-            p7, _ = self.conv(ctx, self.relu(ctx, p6), f.conv7)
-        p5, _ = self.conv(ctx, c5, f.latlayer1)
-        p4, _ = self.conv(ctx, c4, f.latlayer2, res=p5, res_mode=2)
-        p3, _ = self.conv(ctx, c3, f.latlayer3, res=p4, res_mode=2)
-        p5s, _ = self.conv(ctx, p5, f.toplayer0)
-        p4s, _ = self.conv(ctx, p4, f.toplayer1)
-        p3s, _ = self.conv(ctx, p3, f.toplayer2)
-        return [p3s, p4s, p5s, p6, p7]
+            coarse(h)
+            rest(h)
+        return [h["p3s"], h["p4s"], h["p5s"], h["p6"], h["p7"]]
 
     def kp_pyramid(self, ctx, c2, c3, c4, c5):
         """fpn.py:117-124 (fp5 is not smoothed)."""

@@ -1,5 +1,5 @@
 #!/bin/bash
-# P6 / P7 of the detection pyramid on the side stream in the forward pass: parity suites, then step A/B (first call: MPN_P67_SIDE;
+# P6 / P7 of the detection pyramid on the side stream in the forward pass: parity suites, then step A/B (first call: MPN_DET_PYRAMID_SIDE;
 # second call, as committed: the coarse keypoint-head branches, MPN_KP_COARSE_SIDE — neutral, removed again)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/r3p67; mkdir -p $O
