@@ -798,6 +798,12 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
 
     const int u_row = lane >> 2;
     const int u_piece = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
+    // The pixel tile is read at row offsets 0 / 1 / 2 (the three taps).  The generic key g(row >> 2) = (-q) & 3 is conflict-free only
+    // for 16-row-aligned fragments: shifted by one or two rows, two lane pairs of every ds_read_b128 service group ({0-3,12-15,20-27},
+    // ...) meet on a bank quad (PMC: bank-conflict cycles 6.7 % of the kernel against 3.4 % in the generic kernel).  The key
+    // 2 * ((row >> 2) & 1) keeps all 16 (row, piece) pairs of every group on distinct quads for ALL three offsets (exhaustive check
+    // over keys of the row index mod 16: tools/lds_swizzle_search.py).
+    const int u_piece_b = (lane & 3) ^ (((lane >> 4) & 1) << 1);
     unsigned a_voff[LA];
 #pragma unroll
     for (int q = 0; q < LA; ++q) {
@@ -825,7 +831,7 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
             b_bi[q] = (int)bi;
         }
         b_ok[q] = ok;
-        b_base[q] = (unsigned)(((long)pcu * p.x_sW + u_piece * C::V) * TS);
+        b_base[q] = (unsigned)(((long)pcu * p.x_sW + u_piece_b * C::V) * TS);
     }
     const int line_b = (int)(p.W * p.x_sW * TS);                  // bytes between two image lines
 
@@ -847,7 +853,7 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int row = l + d;
-            fb_off[d][j] = row * 64 + (((lane >> 4) ^ ((0 - (row >> 2)) & 3)) * 16);
+            fb_off[d][j] = row * 64 + (((lane >> 4) ^ (((row >> 2) & 1) << 1)) * 16);
         }
         const unsigned pix = (unsigned)p0 + (unsigned)l;
         const unsigned wo = (pix < P ? pix : 0u) % (unsigned)p.Wo;
@@ -884,7 +890,7 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
                     const int hh = b_h[q] + dy;
                     const bool ok = b_ok[q] && (unsigned)hh < (unsigned)p.H;
                     const unsigned src = (unsigned)((b_bi[q] * Hs + (hh >> sh)) * Ws + (b_w[q] >> sh));
-                    const unsigned voff = ok ? (src * (unsigned)pk.kseg_c + (unsigned)(u_piece * C::V)) * TS : 0x80000000u;
+                    const unsigned voff = ok ? (src * (unsigned)pk.kseg_c + (unsigned)(u_piece_b * C::V)) * TS : 0x80000000u;
                     lds_dma16(voff, rs, so, __builtin_amdgcn_readfirstlane(st + (wave_u * LB + q) * 1024u));
                 }
                 done = true;
