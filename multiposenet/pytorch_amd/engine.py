@@ -832,7 +832,11 @@ class Engine(object):
             # workgroups walking 576 / 72 k-steps (190 + 31 us on a nearly empty chip): mode 1 moves just those (-0.13 ms/step),
             # mode 2 the whole pyramid (another -0.06; profiles/r03_forward_side_fork_ab.txt).  `h` keeps every tensor of the branch
             # alive until the join; the tape order (hence the backward pass) is the same as without the fork.
-            self._on_side(ctx, dev, (c3, c4, c5, h), (lambda: (coarse(h), rest(h))) if mode == 2 else (lambda: coarse(h)))
+            def branch():
+                coarse(h)
+                if mode == 2:
+                    rest(h)
+            self._on_side(ctx, dev, (c3, c4, c5, h), branch)
             self.flush_side(ctx, dev)
             ctx.fwd_side_join = True
             if mode != 2:
