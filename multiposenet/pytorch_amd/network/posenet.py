@@ -295,6 +295,7 @@ class poseNet(nn.Module):
         return list(_NetFn.apply(self._anchor, (self, ctx, slots), *raw))
 
     def _finish_forward(self, ctx):
+        self._engine.join_forward_side(ctx, self._arena.flat.device)      # forward work forked to the side stream (Engine.det_pyramid)
         if ctx.bn_train_ran:
             if all(m.training for m in self._bns) and all(m.num_batches_tracked.data_ptr() == self._nbt[i].data_ptr()
                                                           for i, m in enumerate(self._bns)):
