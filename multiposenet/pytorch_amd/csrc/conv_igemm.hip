@@ -139,6 +139,30 @@ __device__ __forceinline__ void store_partial(float* dst, float a, float b, bool
     }
 }
 
+// Atomic batch statistics (mpn.h: stats_atomic): the tile's (sum, sum^2) of one channel go into that channel's two 64-bit fixed-point
+// accumulators.  Integer atomics: the totals are the same whatever order the workgroups arrive in; no return value, so the wave does
+// not wait for them (the end of the kernel does).
+//   mode 1: one accumulator pair per channel, agent-scope atomics.  The XCDs' L2s are not coherent with each other, so an agent-scope
+//           read-modify-write is carried out at the memory side: measured ~12 G atomics/s for the whole chip — 20 us per 30x30 layer,
+//           150 us per 120x120 layer (profiles/r04_bn_atomic_stats_ab.txt).  Correct, deterministic, and far too slow.
+//   mode 2: EIGHT accumulator pairs per channel, one per XCD: a workgroup adds to the copy of the XCD it runs on (HW_REG_XCC_ID, a
+//           hardware fact, not a guess from blockIdx) with workgroup-scope atomics, which the XCD's own L2 carries out at cache speed.
+//           Every address of copy x is only ever touched by waves on XCD x, so no cross-XCD coherence is needed inside the launch;
+//           the kernel-end release writes the lines back and the consumer launch (bn_act_acc) adds the eight copies.
+// One lane = one accumulator (comp 0: sum, 1: sum^2): consecutive lanes hit consecutive 8-byte words, so a wave instruction covers
+// whole 64-byte lines.
+__device__ __forceinline__ void stat_atomic_add(float* stats, int cout, int comp, int Cout, int mode, float v) {
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(stats) + (long)cout * 2 + comp;
+    const long long iv = __double2ll_rn((double)v * (comp ? (double)(1LL << MPN_STAT_SQ_FRAC_BITS) : (double)(1LL << MPN_STAT_SUM_FRAC_BITS)));
+    if (mode == 2) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;          // HW_REG_XCC_ID[3:0]
+        acc += (long)xcc * Cout * 2;
+        __hip_atomic_fetch_add(acc, (unsigned long long)iv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        __hip_atomic_fetch_add(acc, (unsigned long long)iv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // In-launch finalize (mpn.h: fin_*).  Every workgroup of channel tile `tc` has published its partial pair per channel; the one that
 // draws the last ticket reduces the column [ntiles][TC] in a fixed order (SL interleaved slices per channel in double precision,
 // combined in slice order) — the same numbers whichever workgroup arrives last — and writes the BatchNorm coefficients.
@@ -363,7 +387,17 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
             }
         __syncthreads();
         const int t = threadIdx.x;
-        if (t < TC) {
+        if (pk.stats_atomic) {
+            for (int e = t; e < 2 * TC; e += 256) {
+                const int row = e >> 1, comp = e & 1, cout = c0 + row;
+                if (cout < p.Cout) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < C::WAVES_P; ++w) v += sf[(w * TC + row) * 2 + comp];
+                    stat_atomic_add(p.stats, cout, comp, p.Cout, pk.stats_atomic, v);
+                }
+            }
+        } else if (t < TC) {
             const int cout = c0 + t;
             if (cout < p.Cout) {
                 float a = 0.f, q = 0.f;
@@ -376,7 +410,10 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
             }
         }
     };
-    if (GENERAL && p.stats && !(dbg & 64)) {
+    // atomic statistics, order 3: before the stores as well — the memory-side atomics take microseconds to be acknowledged, and a
+    // workgroup cannot retire before they are; issued first, that latency runs under the tile's store phase
+    const bool stats_first = GENERAL || pk.stats_atomic == 3;
+    if (stats_first && p.stats && !(dbg & 64)) {
         tile_stats(lds_f);
         __syncthreads();
     }
@@ -534,7 +571,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
         }
         if (ps + 1 < NPASS) __syncthreads();
     }
-    if (!GENERAL && p.stats && !(dbg & 64)) tile_stats(reinterpret_cast<float*>(lds + 4 * REGION));
+    if (!stats_first && p.stats && !(dbg & 64)) tile_stats(reinterpret_cast<float*>(lds + 4 * REGION));
 
     if (bnb) {
         // lanes sharing a channel chunk (same sc_, different pixel slot sp): butterfly over the sp bits
@@ -1096,6 +1133,7 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     MPN_CHECK_ARG(!p.res_mask || (p.res_mode == 1 && !p.nseg && p.y_sB == (int64_t)p.Ho * p.Wo * p.y_sP && p.y_sP == p.Cout_store));
     MPN_CHECK_ARG(!(p.stats && (p.bias || p.scale || p.res_mode || p.accumulate || p.act)));
     MPN_CHECK_ARG(!((p.res_mode || p.accumulate) && p.act && p.act != 3));
+    MPN_CHECK_ARG(!p.stats_atomic || (p.stats_atomic >= 1 && p.stats_atomic <= 3 && p.stats && !p.fin_counters && !p.nseg));
     MPN_CHECK_ARG(!p.fin_counters || (((p.stats != nullptr) != (p.bnb_partial != nullptr)) && p.fin_count > 0 && !p.nseg &&
                                       (p.stats ? p.fin_out != nullptr : true)));
     if (p.fin_counters && p.fin_group) {                       // two-level finalize: group / channel-tile ticket ranges (mpn.h)

@@ -335,7 +335,7 @@ inline bool pw_shape_ok(const MpnConvParams& p) {
     if (p.dtype == MPN_F32 || p.nseg != 0 || p.R != 1 || p.S != 1 || p.stride != 1 || p.pad != 0) return false;
     if (!(p.Cin == 64 || p.Cin == 128 || p.Cin == 256)) return false;
     if (p.Cout < 256 || (p.Cout & 63) || p.Cout_store != p.Cout || p.out_f32) return false;
-    if (p.res_mode > 1 || p.act == 2 || p.fin_counters || p.res_mask || p.relu_y || p.y2 || p.kseg_n) return false;
+    if (p.res_mode > 1 || p.act == 2 || p.fin_counters || p.res_mask || p.relu_y || p.y2 || p.kseg_n || p.stats_atomic) return false;
     const bool affine = p.scale || p.bias || p.act || p.res_mode;                 // epilogue 1
     const bool grad = p.accumulate || p.bnb_partial;                             // epilogue 2: accumulate AND statistics with the ReLU mask
     if (affine && grad) return false;                                            // read from z — the training gradient of conv1 (fpn.py:14,28);

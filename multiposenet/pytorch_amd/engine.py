@@ -42,6 +42,8 @@ class Ctx(object):
         self.fwd_side_join = False   # forward work is in flight on the side stream (Engine.det_pyramid): join before it is consumed
         self.fin_flags = None    # zeroed flag words of the fused finalize + bn_act launches of this pass (Engine._fin_flag)
         self.fin_flag_next = 0
+        self.stat_acc = None     # int64 [total BatchNorm channels, 2]: this pass's atomic statistics accumulators (Engine._stat_acc)
+        self.stat_acc_next = 0
         self.lazy_res = {}       # id(Act) -> (dz, mask bits): shortcut gradient dz * (z > 0) NOT materialised; the convolution whose
                                  # input gradient completes that Act adds it in its epilogue (Engine.defer_shortcut_grad)
 
@@ -117,6 +119,17 @@ class Engine(object):
         # neutral (41.55 vs 41.67 ms in one call: the pass it removes costs what the extra epilogue load of eight MFMA-bound tower
         # launches costs, which also lose the lighter "plain" kernel): off by default
         self.fuse_relu_bwd = os.environ.get("MPN_FUSE_RELU_BWD", "0") != "0"
+        # training forward: the conv epilogue adds its tile statistics to per-channel 64-bit fixed-point accumulators with integer
+        # atomics (order-independent, deterministic) and bn_act derives the coefficients in its prologue: the finalize launch between
+        # conv and bn_act — 16 us of dependent kernel boundary per BatchNorm layer in a chain that has nothing beside it — is gone.
+        # Layers of [min, max] pixel tiles take this path (below min: the in-launch finalize of ops.FIN_MAX_TILES)
+        self.bn_atomic = os.environ.get("MPN_BN_ATOMIC_STATS", "1") != "0"
+        # 8: one accumulator copy per XCD, added to with workgroup-scope atomics in that XCD's L2 (mpn.h: stats_atomic 2);
+        # 1: a single copy and agent-scope atomics, which the memory side carries out (measured 20 - 150 us per layer: unusable)
+        self.bn_atomic_copies = 8 if os.environ.get("MPN_BN_ATOMIC_XCD", "1") != "0" else 1
+        self.bn_atomic_min_tiles = int(os.environ.get("MPN_BN_ATOMIC_MIN_TILES", "0"))
+        self.bn_atomic_max_tiles = int(os.environ.get("MPN_BN_ATOMIC_MAX_TILES", str(1 << 30)))
+        self._bn_channels = None
 
     def side_stream(self, device):
         """Second HIP stream for weight/bias gradients.  They are off the backward critical path (only the
@@ -282,12 +295,37 @@ class Engine(object):
             return None
         return (bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1, bn.eps)
 
+    def _stat_acc(self, ctx, device):
+        """Allocator of atomic statistics accumulators for this pass (ops.conv_forward(stat_acc=...)): slices of ONE zeroed int64
+        buffer sized for every BatchNorm channel of the model, zeroed by one fill launch when the pass first needs it (a recorded
+        step re-zeroes it on every replay).  None when the atomic path is off."""
+        if not self.bn_atomic:
+            return None
+
+        def take(tiles, C):
+            if tiles < self.bn_atomic_min_tiles or tiles > self.bn_atomic_max_tiles:
+                return None
+            if self._bn_channels is None:
+                self._bn_channels = sum(m.num_features for m in self.m.modules() if isinstance(m, torch.nn.BatchNorm2d))
+            if ctx.stat_acc is None or ctx.stat_acc_next + C * self.bn_atomic_copies * 2 > ctx.stat_acc.numel():
+                n = max(self._bn_channels, C) * self.bn_atomic_copies * 2
+                ctx.stat_acc = torch.empty(n, dtype=torch.int64, device=device)
+                call("mpn_fill_f32", ops.ptr(ctx.stat_acc), 0.0, n * 2, ops.stream_ptr())
+                ctx.stat_acc_next = 0
+                ctx.keep.append(ctx.stat_acc)
+            n = C * self.bn_atomic_copies * 2
+            a = ctx.stat_acc[ctx.stat_acc_next: ctx.stat_acc_next + n]
+            ctx.stat_acc_next += n
+            return a.view(self.bn_atomic_copies, C, 2) if self.bn_atomic_copies > 1 else a.view(C, 2)
+        return take
+
     def conv(self, ctx, x, layer, act=0, res=None, res_mode=0, stats=False, out_f32=False, tag="", bn=None):
         O, I, R, S, stride, pad = _geom(layer)
         bias = layer.bias
         y, st = ops.conv_forward(x, self.w_fwd(layer), O, R, S, stride, pad, bias=bias.data if bias is not None else None,
                                  act=act, res=res, res_mode=res_mode, want_stats=stats, out_f32=out_f32, tag=tag,
-                                 bn_fin=self._bn_fin(bn) if stats else None)
+                                 bn_fin=self._bn_fin(bn) if stats else None,
+                                 stat_acc=self._stat_acc(ctx, x.t.device) if (stats and bn is not None) else None)
         y.relu_out = act == 1
         if ctx.train:
             y.needs_grad = bool(x.needs_grad or layer.weight.requires_grad or (bias is not None and bias.requires_grad)
@@ -489,6 +527,9 @@ class Engine(object):
             momentum = layer.momentum if layer.momentum is not None else 0.1
             if isinstance(stats, ops.BNState):         # the conv launch finalized in place
                 st = stats
+            elif isinstance(stats, ops.StatAcc):       # atomic statistics: coefficients + normalise in one launch
+                z, st = ops.bn_act_acc(y, stats, layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var,
+                                       momentum, layer.eps, relu, res=res, tag=tag, want_mask=want_mask)
             else:
                 fused = None
                 if self.fuse_bn_act_finalize:          # finalize inside the bn_act launch: one kernel boundary less in the forward chain
@@ -756,7 +797,8 @@ class Engine(object):
             z, _ = ops.conv_forward(xa, wp, 64, 7, 1, 2, 0, cin=32, x_geom=geom, out_hw=(Ho, Wo), scale=bst.scale, bias=bst.shift, act=1)
             return self.maxpool(ctx, z)
         y, st = ops.conv_forward(xa, wp, 64, 7, 1, 2, 0, cin=32, x_geom=geom, out_hw=(Ho, Wo), want_stats=bn_train,
-                                 bn_fin=self._bn_fin(f.bn1) if bn_train else None)
+                                 bn_fin=self._bn_fin(f.bn1) if bn_train else None,
+                                 stat_acc=self._stat_acc(ctx, img.device) if bn_train else None)
         if ctx.train and w.requires_grad:
             y.needs_grad = True
             self._note_use(ctx, w)

@@ -402,7 +402,7 @@ def conv_out_hw(H, W, R, S, stride, pad):
 def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, res=None, res_mode=0,
                  want_stats=False, out_f32=False, out=None, accumulate=False, mode=0, out_hw=None,
                  cin=None, x_geom=None, y_geom=None, cout_store=None, needs_grad=False, tag="", bnb=None, bn_fin=None, res_mask=None,
-                 split=None, relu_y=None):
+                 split=None, relu_y=None, stat_acc=None):
     """Implicit-GEMM convolution.  x: Act.  w: compute-dtype tensor laid out [Cout][R][S][Cin].
 
     mode 0 = forward gather, mode 1 = dgrad gather (then ``out_hw`` is the input-gradient size and
@@ -469,9 +469,16 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
     keep = None
     if want_stats:
         tiles = call("mpn_conv_stats_tiles", ctypes.byref(p))
-        stats = torch.empty((tiles, Cout, 2), dtype=torch.float32, device=dev)
-        p.stats = stats.data_ptr()
-        if bn_fin is not None and fin_plan(tiles) is not None and not call("mpn_conv_pw_selected", ctypes.byref(p)):
+        acc = stat_acc(tiles, Cout) if stat_acc is not None else None
+        if acc is not None:
+            # atomic statistics (mpn.h: stats_atomic): every workgroup adds its tile's (sum, sum^2) to ONE pair of fixed-point
+            # accumulators per channel; bn_act_acc derives the coefficients itself — no partial table, no finalize launch
+            stats = StatAcc(acc, x.B * Ho * Wo)
+            p.stats, p.stats_atomic = acc.data_ptr(), (2 if acc.dim() == 3 else STAT_ATOMIC_MODE)
+        else:
+            stats = torch.empty((tiles, Cout, 2), dtype=torch.float32, device=dev)
+            p.stats = stats.data_ptr()
+        if acc is None and bn_fin is not None and fin_plan(tiles) is not None and not call("mpn_conv_pw_selected", ctypes.byref(p)):
             # the last workgroup of every channel tile turns the tile partials into the BatchNorm coefficients (no finalize launch):
             # the BNState comes back in the stats slot
             gamma, beta, rm, rv, momentum, eps = bn_fin
@@ -662,6 +669,18 @@ def fin_counters(device):
     return t
 
 
+STAT_ATOMIC_MODE = int(os.environ.get("MPN_BN_ATOMIC_MODE", "1"))      # 1: atomics after the tile's stores, 3: before them
+
+
+class StatAcc(object):
+    """Atomic batch statistics of one BatchNorm input: ``acc`` = int64 [C, 2] fixed-point totals, or [8, C, 2] per-XCD copies
+    (mpn.h: stats_atomic 1 / 2)."""
+    __slots__ = ("acc", "count")
+
+    def __init__(self, acc, count):
+        self.acc, self.count = acc, count
+
+
 class BNState(object):
     __slots__ = ("mean", "invstd", "scale", "shift")
 
@@ -695,6 +714,21 @@ def bn_act(y, st, relu, res=None, needs_grad=False, tag="", want_mask=False):
     call("mpn_bn_act_forward", ptr(y.t), ptr(res.t) if res is not None else None, ptr(z.t), ptr(st.scale), ptr(st.shift),
          y.P, y.C, y.Cs, 1 if relu else 0, dtype_code(y.t.dtype), ptr(z.mask), stream_ptr())
     return z
+
+
+def bn_act_acc(y, sacc, gamma, beta, rm, rv, momentum, eps, relu, res=None, needs_grad=False, tag="", want_mask=False):
+    """Training-mode z = act(bn(y) [+ res]) from atomic statistics (mpn.h: mpn_bn_act_acc_forward): coefficients, running
+    statistics and the normalise pass in ONE launch.  Returns (z, BNState)."""
+    assert sacc.count == y.P and sacc.acc.shape[-2] == y.C and sacc.acc.is_contiguous()
+    copies = sacc.acc.shape[0] if sacc.acc.dim() == 3 else 1
+    st = BNState(y.C, y.t.device)
+    z = Act(torch.empty_like(y.t), y.C, needs_grad, tag)
+    if want_mask and relu:
+        z.mask = torch.empty((y.P, y.Cs // (4 if y.t.dtype == torch.float32 else 8)), dtype=torch.uint8, device=y.t.device)
+    call("mpn_bn_act_acc_forward", ptr(y.t), ptr(res.t) if res is not None else None, ptr(z.t), y.P, y.C, y.Cs, 1 if relu else 0,
+         dtype_code(y.t.dtype), ptr(z.mask), ptr(sacc.acc), copies, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), momentum, eps,
+         ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), stream_ptr())
+    return z, st
 
 
 def bn_act_finalize(y, stats, gamma, beta, rm, rv, momentum, eps, relu, flag, res=None, needs_grad=False, tag="", want_mask=False):

@@ -1,0 +1,142 @@
+"""Round-4 CPU tests: the gradient reducer's schedule for the headline R101 step, and the code-object resource gate (no scratch,
+expected occupancy class) for the hot kernels of the built library."""
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from helpers import ROOT
+
+
+# ------------------------------------------------------------------------------------------------ reducer schedule (R101)
+def _forward_order(m):
+    """Parameters in the order the headline step's forward uses them (engine.backbone -> kp_pyramid -> keypoint_head -> det_pyramid ->
+    detection_head; the reference: fpn.py:97-126, posenet.py:288-335).  Backward completes them in the reverse order."""
+    f = m.fpn
+    mods = [f.conv1, f.bn1]
+    for layer in (f.layer1, f.layer2, f.layer3, f.layer4):
+        for blk in layer:
+            mods += [blk.conv1, blk.bn1, blk.conv2, blk.bn2]
+            if len(blk.downsample) > 0:
+                mods += [blk.downsample[0], blk.downsample[1]]
+            mods += [blk.conv3, blk.bn3]
+    mods += [f.toplayer, f.flatlayer1, f.flatlayer2, f.flatlayer3, f.smooth1, f.smooth2, f.smooth3]
+    mods += [m.convfin_k2, m.convfin_k3, m.convfin_k4, m.convfin_k5, m.convt1, m.convs1, m.convt2, m.convs2, m.convt3, m.convs3, m.convt4, m.convs4,
+             m.conv2, m.convfin]
+    mods += [f.conv6, f.conv7, f.latlayer1, f.latlayer2, f.latlayer3, f.toplayer0, f.toplayer1, f.toplayer2]
+    rm, cm = m.regressionModel, m.classificationModel
+    mods += [rm.conv1, rm.conv2, rm.conv3, rm.conv4, rm.output, cm.conv1, cm.conv2, cm.conv3, cm.conv4, cm.output]
+    out = []
+    for mod in mods:
+        out += [p for p in mod.parameters(recurse=False)]
+    return out
+
+
+def test_grad_reducer_schedule_for_r101_covers_every_trainable_element_once_in_reverse_forward_order(tmp_path):
+    """datasets/data_parallel.py:16-87 reduce-adds every gradient after backward; here buckets are arena slices launched while
+    backward runs.  For the headline model (R101, every non-PRN parameter trainable): (1) the buckets tile the trainable part of
+    the gradient arena exactly — every trainable element in exactly one bucket, no frozen (PRN) element in any; (2) fed the
+    parameters in the order the backward pass completes them, EVERY bucket launches from ``param_ready`` (``finish`` has nothing
+    left to flush), each at the moment its earliest-in-forward parameter completes, so the launch order is the reverse forward
+    order; (3) the collectives are spread over backward instead of bunched at its end: when backward reaches layer1 more than
+    85 % of the gradient bytes are already in flight — only the last bucket (stem .. layer2, the first 32 MB of the arena) has to
+    wait for the end of backward."""
+    from multiposenet.pytorch_amd import ddp
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    store = dist.FileStore(str(tmp_path / "store"), 1)
+    dist.init_process_group("gloo", store=store, rank=0, world_size=1)
+    try:
+        m = poseNet(101, device="cpu") if "device" in poseNet.__init__.__code__.co_varnames else poseNet(101)
+        for p in m.prn.parameters():
+            p.requires_grad = False
+        red = ddp.attach(m, bucket_mb=32.0, broadcast=False)
+        ar = m._arena
+        # (1) coverage
+        cover = torch.zeros(ar.total, dtype=torch.int16)
+        for b in red.buckets:
+            cover[b["start"]: b["end"]] += 1
+        want = torch.zeros(ar.total, dtype=torch.int16)
+        n_train = 0
+        for i, p in enumerate(ar.params):
+            if p.requires_grad:
+                want[ar.offsets[i]: ar.offsets[i] + (ar.sizes[i] + 63) // 64 * 64] = 1
+                n_train += ar.sizes[i]
+        assert torch.equal(cover, want), "buckets do not tile the trainable gradient ranges exactly once"
+        assert abs(n_train - 61.05e6) < 0.05e6, "R101 trainable elements: %d" % n_train
+        seen = sorted(i for b in red.buckets for i in b["params"])
+        assert seen == [i for i, p in enumerate(ar.params) if p.requires_grad]
+        # (2) readiness-driven launch order
+        fwd = _forward_order(m)
+        assert sorted(ar.index[id(p)] for p in fwd) == seen, "the forward order must list every trainable parameter once"
+        pos = {ar.index[id(p)]: k for k, p in enumerate(fwd)}
+        launched = []
+        red._launch = lambda bk: (launched.append(red.buckets.index(bk)), bk.__setitem__("pending", -1), setattr(red, "launched", red.launched + 1))
+        red.begin()
+        bytes_at = {}
+        for p in reversed(fwd):
+            red.param_ready(p)
+            bytes_at[ar.index[id(p)]] = sum(red.buckets[b]["end"] - red.buckets[b]["start"] for b in launched)
+        assert sorted(launched) == list(range(len(red.buckets))), "a bucket never became ready from param_ready: finish() would flush it at the end"
+        first = [min(pos[i] for i in red.buckets[b]["params"]) for b in launched]
+        assert first == sorted(first, reverse=True), "buckets must launch in reverse forward order"
+        # (3) overlap: bytes in flight when backward reaches layer1 / the stem
+        total = sum(b["end"] - b["start"] for b in red.buckets)
+        at_layer1 = bytes_at[ar.index[id(m.fpn.layer1[-1].bn3.bias)]] / float(total)
+        at_stem = bytes_at[ar.index[id(m.fpn.bn1.bias)]] / float(total)
+        assert at_stem > 0.85 and at_layer1 > 0.85, (at_layer1, at_stem)
+        assert len(red.buckets) >= 7
+    finally:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ code-object resource gate
+def _hot_kernels():
+    """(mangled-name fragment, minimum waves per SIMD the schedule was tuned for, LDS bytes or None) — DESIGN.md section 3."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from codeobj import mangled
+    hot = []
+    for k in ("conv_igemm_kernel", "conv_igemm_s3_kernel"):
+        for gen in (False, True):
+            hot.append((mangled(k, "t", 128, 128, False, gen, False), 3, 49152))     # 3 workgroups / CU (LDS: 3 x 48 KB)
+            hot.append((mangled(k, "t", 256, 128, False, gen, False), 2, 73728))     # 2 workgroups / CU
+            hot.append((mangled(k, "t", 64, 128, False, gen, False), 3, 36864))
+    hot.append((mangled("conv_igemm_s3_kernel", "t", 256, 128, False, True, True), 1, 73728))      # conv2: the virtual concatenation
+    for tm, tn, lds in ((128, 128, 49152), (128, 64, 36864), (64, 128, 36864), (64, 64, 24576)):
+        hot.append((mangled("conv_wgrad_dma_kernel", tm, tn), 3, lds))
+    hot.append((mangled("conv_wgrad_dma_seg_kernel", 128, 128), 3, 49152))
+    for k, w in (("bn_act_kernel", 8), ("bn_act_acc_kernel", 8), ("bn_bwd_apply_kernel", 5), ("relu_bwd_kernel", 8), ("maxpool_fwd_kernel", 4)):
+        hot.append((mangled(k, "t"), w, None))
+    return hot
+
+
+def test_hot_kernels_have_no_scratch_and_keep_their_occupancy_class():
+    """Round 3 lost 3.3 ms/step to 62 - 112 spilled VGPRs in the 128-row conv tiles before anyone noticed (three epilogue features
+    had been compiled into one kernel).  This gate reads the code objects of the BUILT library (tools/codeobj.py: the
+    NT_AMDGPU_METADATA note of every gfx950 ELF in .hip_fatbin) and fails when a kernel the training / inference steps launch
+    by default has a scratch segment, a spilled register, fewer register-limited waves per SIMD than its schedule was tuned for,
+    or another LDS footprint (= another number of workgroups per CU)."""
+    import sys
+    from multiposenet.pytorch_amd import _lib
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import codeobj
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    ks = codeobj.kernels(_lib.LIB_PATH)
+    assert len(ks) > 100
+    bad = []
+    for frag, min_waves, lds in _hot_kernels():
+        hits = [k for k in ks if frag in k["name"]]
+        assert hits, "no kernel matches %s in %s (renamed? update the gate)" % (frag, _lib.LIB_PATH)
+        for k in hits:
+            waves = codeobj.waves_per_simd(k["vgpr"] + k["agpr"])
+            if k["scratch"] or k["spill_v"] or k["spill_s"] or waves < min_waves or (lds is not None and k["lds"] != lds):
+                bad.append("%s: vgpr %d scratch %d spill v%d s%d waves/SIMD %d (want >= %d) lds %d (want %s)"
+                           % (k["name"], k["vgpr"], k["scratch"], k["spill_v"], k["spill_s"], waves, min_waves, k["lds"], lds))
+    assert not bad, "hot kernels lost their register / LDS budget:\n" + "\n".join(bad)
+    # nothing in the library may use a stack (dynamic or fixed scratch beyond spills would mean recursion / big local arrays)
+    stacky = [k["name"] for k in ks if k["scratch"] > 1024]
+    assert not stacky, "kernels with > 1 KB of scratch per lane: %s" % stacky

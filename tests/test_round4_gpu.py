@@ -1,0 +1,226 @@
+"""Round-4 GPU tests: atomic (fixed-point) BatchNorm batch statistics and the launch that consumes them."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import check_close, from_act, report, rnd, rng_normal, to_act, w_krsc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "GPU tests selected but no GPU is visible"
+    from multiposenet.pytorch_amd import _lib
+    _lib.lib()
+
+
+def _acc_alloc(C, copies):
+    acc = torch.zeros((copies, C, 2) if copies > 1 else (C, 2), dtype=torch.int64, device="cuda")
+    return acc, (lambda tiles, c: acc)
+
+
+# ------------------------------------------------------------------------------------------------ atomic statistics
+@pytest.mark.parametrize("copies", [1, 8])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 30, 30, 64, 256, 1), (3, 17, 19, 128, 128, 3), (1, 40, 40, 256, 1024, 1), (2, 8, 8, 64, 64, 3), (8, 120, 120, 64, 64, 1)])
+def test_conv_atomic_statistics_equal_the_tile_table(dtype, case, copies):
+    """fpn.py:28-34 in training mode.  The conv epilogue adds (sum, sum^2) of its tile to one pair of 64-bit fixed-point accumulators
+    per channel (mpn.h: stats_atomic) instead of writing a [tiles][C][2] table: the totals must equal the table's column sums to the
+    fixed-point resolution (2^-28 / 2^-20 per tile, rounded to nearest), be bit-identical from run to run (integer adds commute),
+    and leave the output tensor untouched.  copies = 8: one accumulator copy per XCD, workgroup-scope atomics (stats_atomic 2) — the
+    900-tile case spreads its workgroups over all eight XCDs, so a copy shared by two XCDs would show as a wrong total."""
+    from multiposenet.pytorch_amd import ops
+    B, H, W, Cin, Cout, k = case
+    x = rnd(dtype, rng_normal(11, B, Cin, H, W))
+    w = rnd(dtype, rng_normal(12, Cout, Cin, k, k) / float(np.sqrt(Cin * k * k)))
+    y0, table = ops.conv_forward(to_act(x, dtype), w_krsc(w, dtype), Cout, k, k, 1, k // 2, want_stats=True)
+    tiles = table.shape[0]
+    runs = []
+    for _ in range(3):
+        acc, alloc = _acc_alloc(Cout, copies)
+        y1, sa = ops.conv_forward(to_act(x, dtype), w_krsc(w, dtype), Cout, k, k, 1, k // 2, want_stats=True, stat_acc=alloc)
+        assert isinstance(sa, ops.StatAcc) and sa.count == B * H * W
+        torch.cuda.synchronize()
+        assert torch.equal(y1.t, y0.t), "the statistics mode changed the convolution output"
+        runs.append(acc.clone() if copies == 1 else acc.sum(0))
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), "atomic statistics differ from run to run"
+    tot = table.double().sum(0).cpu()
+    got1 = runs[0][:, 0].double().cpu() / 2.0 ** 28
+    got2 = runs[0][:, 1].double().cpu() / 2.0 ** 20
+    e1 = float((got1 - tot[:, 0]).abs().max()); e2 = float((got2 - tot[:, 1]).abs().max())
+    report("atomic stats %s %s: tiles %d  |sum err| %.3e (lim %.3e)  |sumsq err| %.3e (lim %.3e)" % (case, dtype, tiles, e1, tiles * 2.0 ** -29, e2, tiles * 2.0 ** -21))
+    assert e1 <= tiles * 2.0 ** -29 + 1e-12 and e2 <= tiles * 2.0 ** -21 + 1e-12
+
+
+@pytest.mark.parametrize("copies", [1, 8])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [64, 256, 1024, 2048])
+def test_bn_act_from_atomic_statistics_equals_finalize_plus_bn_act(dtype, C, copies):
+    """mpn_bn_act_acc_forward == mpn_bn_finalize_train + mpn_bn_act_forward (coefficients, running statistics, z, mask bits), and
+    both == torch's F.batch_norm in training mode within the kernel tolerances of test_batchnorm_train_and_eval."""
+    from multiposenet.pytorch_amd import ops
+    B, H, W = 2, 21, 13
+    P = B * H * W
+    y = rnd(dtype, rng_normal(41, B, C, H, W) * 1.5 + 0.3)
+    res = rnd(dtype, rng_normal(42, B, C, H, W))
+    gamma = torch.rand(C, generator=torch.Generator().manual_seed(43)) + 0.5
+    beta = rng_normal(44, C) * 0.1
+    rm0, rv0 = rng_normal(45, C) * 0.1, torch.rand(C, generator=torch.Generator().manual_seed(46)) + 0.5
+    ya = to_act(y, dtype)
+    yv = from_act(ya).double()
+    s1, s2 = yv.sum((0, 2, 3)), (yv * yv).sum((0, 2, 3))
+    table = torch.stack([s1, s2], 1).float().unsqueeze(0).contiguous().cuda()
+    acc = torch.stack([torch.round(table[0, :, 0].double() * 2.0 ** 28), torch.round(table[0, :, 1].double() * 2.0 ** 20)], 1).to(torch.int64).contiguous()
+    if copies > 1:              # split the totals unevenly over the copies (some negative): the consumer must add them as integers
+        parts = [acc // 3, acc - acc // 3 + 12345, torch.full_like(acc, -12345)] + [torch.zeros_like(acc)] * (copies - 3)
+        acc = torch.stack(parts).contiguous()
+    for relu, use_res in ((True, False), (True, True), (False, False)):
+        rm, rv = rm0.clone(), rv0.clone()
+        z = F.batch_norm(y.clone(), rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+        if use_res:
+            z = z + res
+        if relu:
+            z = F.relu(z)
+        ra = to_act(res, dtype) if use_res else None
+        rmA, rvA = rm0.clone().cuda(), rv0.clone().cuda()
+        stA = ops.bn_finalize_train(table, P, gamma.cuda(), beta.cuda(), rmA, rvA)
+        zA = ops.bn_act(ya, stA, relu, res=ra, want_mask=relu)
+        rmB, rvB = rm0.clone().cuda(), rv0.clone().cuda()
+        zB, stB = ops.bn_act_acc(ya, ops.StatAcc(acc, P), gamma.cuda(), beta.cuda(), rmB, rvB, 0.1, 1e-5, relu, res=ra, want_mask=relu)
+        torch.cuda.synchronize()
+        for name, a, b in (("mean", stA.mean, stB.mean), ("invstd", stA.invstd, stB.invstd), ("scale", stA.scale, stB.scale),
+                           ("shift", stA.shift, stB.shift), ("running_mean", rmA, rmB), ("running_var", rvA, rvB)):
+            err = float((a - b).abs().max()); lim = 2e-6 * max(float(a.abs().max()), 1e-3)
+            assert err <= lim, "%s: atomic path differs from the finalize launch by %.3e (> %.3e)" % (name, err, lim)
+        check_close("bn_act_acc fwd C=%d relu=%s res=%s %s" % (C, relu, use_res, dtype), from_act(zB), z, dtype)
+        check_close("bn_act_acc vs bn_act", from_act(zB), from_act(zA), dtype, factor=0.02)
+        check_close("bn_act_acc running_mean", rmB.cpu(), rm, torch.float32)
+        check_close("bn_act_acc running_var", rvB.cpu(), rv, torch.float32)
+        if relu:
+            diff = int((zA.mask != zB.mask).sum())
+            assert diff <= zA.mask.numel() // 1000, "mask bits differ in %d of %d bytes" % (diff, zA.mask.numel())
+
+
+def test_training_step_with_atomic_statistics_matches_the_finalize_launches_and_is_reproducible():
+    """Whole network (R50 train_both... keypoint + detection losses, batch-statistics BatchNorm, fp32): with the atomic statistics on,
+    loss, heat-maps, running statistics and every parameter gradient equal those of the finalize-launch path within fp32 rounding
+    noise, and two runs of the atomic path are bit-identical (integer atomics commute; the reference's own cuDNN statistics are not)."""
+    from test_model_gpu import get_model, t
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    from oracle import weightgen
+    B, S = 2, 128
+    img = t(weightgen.gen_images(410, B, S, S)).cuda()
+    heat, wgt = (t(a).cuda() for a in weightgen.gen_keypoint_gt(411, B, S // 4, S // 4))
+    out = {}
+    for mode in ("0", "1", "1"):
+        m = get_model(50, torch.float32)
+        default = m._engine.bn_atomic
+        m._engine.bn_atomic = mode == "1"
+        for p in m.prn.parameters():
+            p.requires_grad = False
+        m.train()
+        m._arena.ensure_grads()
+        m._arena.grad_flat.zero_()
+        pred, saved = m([img, "keypoint_subnet"])
+        loss, _ = poseNet.build_loss(saved, "keypoint_subnet", heat, wgt)
+        loss.backward()
+        torch.cuda.synchronize()
+        m._engine.bn_atomic = default
+        rs = torch.cat([v.flatten().float() for k, v in sorted(m.state_dict().items()) if "running_" in k])
+        out.setdefault(mode, []).append((pred.detach().clone(), float(loss), m._arena.grad_flat.clone(), rs.clone()))
+    (p0, l0, g0, r0), = out["0"]
+    (p1, l1, g1, r1), (p2, l2, g2, r2) = out["1"]
+    assert torch.equal(p1, p2) and l1 == l2 and torch.equal(g1, g2) and torch.equal(r1, r2), "atomic-statistics step is not bit-reproducible"
+    rel = abs(l1 - l0) / abs(l0)
+    perr = float((p1 - p0).abs().max())
+    gerr = float((g1 - g0).norm() / g0.norm())
+    rerr = float((r1 - r0).abs().max())
+    report("atomic BN statistics vs finalize launches (R50 kp 128x128 B=2 fp32): loss rel %.2e, heat-map abs %.2e, grad rel-L2 %.2e, running stats abs %.2e"
+           % (rel, perr, gerr, rerr))
+    assert rel <= 1e-5 and perr <= 1e-4 and gerr <= 1e-3 and rerr <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ TTA driver vs the real Tester
+def test_tta_driver_matches_the_real_reference_tester(tmp_path):
+    """evaluate/tester.py:131-193,256-331.  tests/golden/make_golden_tta.py drove the REAL reference ``Tester`` (coco_eval,
+    _get_multiplier, _get_outputs, _handle_heat, crop_with_factor, get_joint_list) with the stand-in model of tests/tta_standin.py
+    on two images; the product ``Tester`` driven with the same stand-in on the device must reproduce: the scale list, the padded
+    network input shape of every scale (pad-to-32, which side the scaling is based on), every scale's person boxes, the averaged
+    maps of the original pass, the channel sums of the flipped pass, the flip/swap average, the joints and the boxes handed to
+    prn_process (index 1 of the original pass, neck removed) and the result file in COCO keypoint order.  cv2.resize is the
+    oracle's restatement on the reference side and mpn_resize here (both unpinned against OpenCV itself): the
+    fixture pins the driver's control flow, with tolerances that cover float32-vs-float64 accumulation only."""
+    import json
+    from helpers import GOLD, gold
+    import tta_standin
+    from multiposenet.pytorch_amd.evaluate.tester import Tester, TestParams
+    g = gold("g15_tta.npz")
+    fixture = json.load(open(os.path.join(GOLD, "g15_tta_results.json")))
+    calls, prn_args = [], []
+
+    def model(inputs):
+        im, subnet = inputs
+        assert subnet == "both" and im.is_cuda
+        calls.append(tuple(int(v) for v in im.shape))
+        heat, (s, c, b) = tta_standin.standin_outputs(im)
+        return heat, (s, c, b)
+    t = Tester.__new__(Tester)
+    t.params = TestParams()
+    t.params.inp_size = 48
+    t.params.coco_result_filename = str(tmp_path / "results.json")
+    t.params.testresult_write_json = True
+    t.dev = torch.device("cuda", 0)
+    t.model = model
+    t.prn_process = lambda kps, boxes, name, image_id=0: (prn_args.append((kps, boxes, name, image_id)) or
+                                                         tta_standin.fake_prn_results(kps, boxes, name, image_id))
+    worst = {"heat": 0.0, "avg": 0.0, "box": 0.0}
+    for tag in ("a", "b"):
+        img = torch.from_numpy(g["img_" + tag]).cuda()
+        mult = t._get_multiplier(img)
+        assert np.allclose(mult, g["multiplier_" + tag], rtol=0, atol=1e-12), "scale list differs"
+        del calls[:]
+        heat, bbox_all = t._get_outputs(mult, img)
+        assert calls == [tuple(r) for r in g["shapes_" + tag].tolist()], "network input shapes %s != reference %s" % (calls, g["shapes_" + tag].tolist())
+        del calls[:]
+        fheat, fbbox_all = t._get_outputs(mult, img.flip(1).contiguous())
+        assert calls == [tuple(r) for r in g["shapes_flip_" + tag].tolist()]
+        assert [len(b) for b in bbox_all] == g["bbox_counts_" + tag].tolist(), "boxes kept per scale differ"
+        flat = np.array([v for b in bbox_all for v in b], dtype=np.float64).reshape(-1, 4)
+        fflat = np.array([v for b in fbbox_all for v in b], dtype=np.float64).reshape(-1, 4)
+        worst["box"] = max(worst["box"], float(np.abs(flat - g["bbox_" + tag]).max()), float(np.abs(fflat - g["bbox_flip_" + tag]).max()))
+        worst["heat"] = max(worst["heat"], float(np.abs(heat.cpu().numpy() - g["heat_" + tag]).max()))
+        fs = fheat.sum((0, 1)).cpu().numpy()
+        assert np.allclose(fs, g["heat_flip_sum_" + tag], rtol=1e-5), "flipped pass differs"
+        avg = t._handle_heat(heat, fheat)
+        worst["avg"] = max(worst["avg"], float(np.abs(avg.cpu().numpy() - g["heat_avg_" + tag]).max()))
+    assert worst["heat"] <= 2e-5 and worst["avg"] <= 2e-5 and worst["box"] <= 1e-3, worst
+    # ---- the whole loop (Tester.coco_eval from the decoded images on)
+    images = [(11, "img11.jpg", g["img_a"]), (22, "img22.jpg", g["img_b"])]
+    results = t.coco_eval(images)
+    assert len(prn_args) == int(g["n_images"])
+    moved = 0
+    for i, (kps, boxes, name, image_id) in enumerate(prn_args):
+        ref_k, ref_b = g["prn_kps_%d" % i], g["prn_boxes_%d" % i]
+        assert image_id == int(g["prn_id_%d" % i]) and name == images[i][1]
+        got_b = np.array(boxes, dtype=np.float64).reshape(-1, 4)
+        assert got_b.shape == ref_b.shape and np.abs(got_b - ref_b).max() <= 1e-3, "prn_process got another scale's boxes"
+        got_k = np.array(kps, dtype=np.float64).reshape(-1, 5)
+        assert got_k.shape == ref_k.shape, "image %d: %d joints, reference %d" % (i, got_k.shape[0], ref_k.shape[0])
+        assert np.array_equal(got_k[:, 3:], ref_k[:, 3:]), "joint ids / types differ (neck removal, type shift)"
+        assert np.abs(got_k[:, 2] - ref_k[:, 2]).max() <= 1e-4, "peak scores differ"
+        d = np.abs(got_k[:, :2] - ref_k[:, :2])
+        assert d.max() <= 1.0, "peak coordinates differ by more than a pixel"
+        moved += int((d > 0).sum())
+    ref_res = fixture["results"]
+    assert len(results) == len(ref_res)
+    on_disk = json.load(open(t.params.coco_result_filename))
+    for r, q, o in zip(results, ref_res, on_disk):
+        assert r["image_id"] == q["image_id"] and r["file_name"] == q["file_name"] and r["category_id"] == q["category_id"]
+        assert r["keypoints"] == q["keypoints"] == o["keypoints"], "COCO keypoint order differs"
+        assert r["score"] == q["score"] and np.abs(np.array(r["bbox"]) - np.array(q["bbox"])).max() <= 1e-3
+    report("TTA driver vs the real Tester (2 images, 5 scales x flip): heat %.2e, average %.2e, boxes %.2e abs; %d joints, %d coordinates off by one pixel"
+           % (worst["heat"], worst["avg"], worst["box"], sum(len(a[0]) for a in prn_args), moved))
