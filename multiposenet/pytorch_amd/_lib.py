@@ -105,7 +105,7 @@ SIGNATURES = {
     "mpn_bn_finalize_train": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "mpn_bn_finalize_eval": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "mpn_bn_act_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
-    "mpn_bn_act_acc_forward": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "mpn_bn_act_acc_forward": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "mpn_bn_act_finalize_supported": (_i, [_i64, _i, _i, _i]),
     "mpn_bn_act_finalize_forward": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mpn_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _vp]),

@@ -141,26 +141,18 @@ __device__ __forceinline__ void store_partial(float* dst, float a, float b, bool
 
 // Atomic batch statistics (mpn.h: stats_atomic): the tile's (sum, sum^2) of one channel go into that channel's two 64-bit fixed-point
 // accumulators.  Integer atomics: the totals are the same whatever order the workgroups arrive in; no return value, so the wave does
-// not wait for them (the end of the kernel does).
-//   mode 1: one accumulator pair per channel, agent-scope atomics.  The XCDs' L2s are not coherent with each other, so an agent-scope
-//           read-modify-write is carried out at the memory side: measured ~12 G atomics/s for the whole chip — 20 us per 30x30 layer,
-//           150 us per 120x120 layer (profiles/r04_bn_atomic_stats_ab.txt).  Correct, deterministic, and far too slow.
-//   mode 2: EIGHT accumulator pairs per channel, one per XCD: a workgroup adds to the copy of the XCD it runs on (HW_REG_XCC_ID, a
-//           hardware fact, not a guess from blockIdx) with workgroup-scope atomics, which the XCD's own L2 carries out at cache speed.
-//           Every address of copy x is only ever touched by waves on XCD x, so no cross-XCD coherence is needed inside the launch;
-//           the kernel-end release writes the lines back and the consumer launch (bn_act_acc) adds the eight copies.
-// One lane = one accumulator (comp 0: sum, 1: sum^2): consecutive lanes hit consecutive 8-byte words, so a wave instruction covers
-// whole 64-byte lines.
-__device__ __forceinline__ void stat_atomic_add(float* stats, int cout, int comp, int Cout, int mode, float v) {
+// not wait for them (the end of the kernel does).  One lane = one accumulator (comp 0: sum, 1: sum^2): consecutive lanes hit
+// consecutive 8-byte words, so a wave instruction covers whole lines (two atomics per lane at a 16-byte stride cost 1.8 ms/step
+// more: profiles/r04_bn_atomic_stats_ab.txt).  The XCDs' L2s are not coherent with each other, so the hardware carries every
+// global atomic out at the memory side whatever scope the source asks for (the ISA has one scope bit for atomics, device / system:
+// hipcc emits the same global_atomic_add_x2 for workgroup and agent scope) — microseconds until acknowledged, and a workgroup
+// cannot retire before that.  Hence the statistics run BEFORE the tile's stores here: the acknowledgement latency passes under the
+// store phase (-0.12 ms/step against atomics issued last).  A per-XCD copy of the accumulators (chosen by HW_REG_XCC_ID) was
+// correct and SLOWER (+0.9 ms/step: eight times the lines for the consumer to read and to zero, no cheaper atomics).
+__device__ __forceinline__ void stat_atomic_add(float* stats, int cout, int comp, float v) {
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(stats) + (long)cout * 2 + comp;
     const long long iv = __double2ll_rn((double)v * (comp ? (double)(1LL << MPN_STAT_SQ_FRAC_BITS) : (double)(1LL << MPN_STAT_SUM_FRAC_BITS)));
-    if (mode == 2) {
-        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;          // HW_REG_XCC_ID[3:0]
-        acc += (long)xcc * Cout * 2;
-        __hip_atomic_fetch_add(acc, (unsigned long long)iv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else {
-        __hip_atomic_fetch_add(acc, (unsigned long long)iv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    __hip_atomic_fetch_add(acc, (unsigned long long)iv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // In-launch finalize (mpn.h: fin_*).  Every workgroup of channel tile `tc` has published its partial pair per channel; the one that
@@ -394,7 +386,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                     float v = 0.f;
 #pragma unroll
                     for (int w = 0; w < C::WAVES_P; ++w) v += sf[(w * TC + row) * 2 + comp];
-                    stat_atomic_add(p.stats, cout, comp, p.Cout, pk.stats_atomic, v);
+                    stat_atomic_add(p.stats, cout, comp, v);
                 }
             }
         } else if (t < TC) {
@@ -410,9 +402,8 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
             }
         }
     };
-    // atomic statistics, order 3: before the stores as well — the memory-side atomics take microseconds to be acknowledged, and a
-    // workgroup cannot retire before they are; issued first, that latency runs under the tile's store phase
-    const bool stats_first = GENERAL || pk.stats_atomic == 3;
+    // atomic statistics: before the stores as well (see stat_atomic_add)
+    const bool stats_first = GENERAL || pk.stats_atomic != 0;
     if (stats_first && p.stats && !(dbg & 64)) {
         tile_stats(lds_f);
         __syncthreads();
@@ -1133,7 +1124,7 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     MPN_CHECK_ARG(!p.res_mask || (p.res_mode == 1 && !p.nseg && p.y_sB == (int64_t)p.Ho * p.Wo * p.y_sP && p.y_sP == p.Cout_store));
     MPN_CHECK_ARG(!(p.stats && (p.bias || p.scale || p.res_mode || p.accumulate || p.act)));
     MPN_CHECK_ARG(!((p.res_mode || p.accumulate) && p.act && p.act != 3));
-    MPN_CHECK_ARG(!p.stats_atomic || (p.stats_atomic >= 1 && p.stats_atomic <= 3 && p.stats && !p.fin_counters && !p.nseg));
+    MPN_CHECK_ARG(!p.stats_atomic || (p.stats_atomic == 1 && p.stats && !p.fin_counters && !p.nseg));
     MPN_CHECK_ARG(!p.fin_counters || (((p.stats != nullptr) != (p.bnb_partial != nullptr)) && p.fin_count > 0 && !p.nseg &&
                                       (p.stats ? p.fin_out != nullptr : true)));
     if (p.fin_counters && p.fin_group) {                       // two-level finalize: group / channel-tile ticket ranges (mpn.h)

@@ -122,13 +122,12 @@ class Engine(object):
         # training forward: the conv epilogue adds its tile statistics to per-channel 64-bit fixed-point accumulators with integer
         # atomics (order-independent, deterministic) and bn_act derives the coefficients in its prologue: the finalize launch between
         # conv and bn_act — 16 us of dependent kernel boundary per BatchNorm layer in a chain that has nothing beside it — is gone.
-        # Layers of [min, max] pixel tiles take this path (below min: the in-launch finalize of ops.FIN_MAX_TILES)
+        # The atomics are carried out at the memory side (~10 us per 30x30 layer even packed into whole lines), so the gain is a
+        # fraction of the 1.6 ms the launches cost: -0.2 ms/step for layers of 65 .. 1000 pixel tiles (30x30, 60x60), a LOSS beyond
+        # (120x120: 3600 tiles x C x 2 atomics, +0.4 ms) and below (<= 64 tiles: the in-launch finalize of ops.FIN_MAX_TILES is cheaper)
         self.bn_atomic = os.environ.get("MPN_BN_ATOMIC_STATS", "1") != "0"
-        # 8: one accumulator copy per XCD, added to with workgroup-scope atomics in that XCD's L2 (mpn.h: stats_atomic 2);
-        # 1: a single copy and agent-scope atomics, which the memory side carries out (measured 20 - 150 us per layer: unusable)
-        self.bn_atomic_copies = 8 if os.environ.get("MPN_BN_ATOMIC_XCD", "1") != "0" else 1
-        self.bn_atomic_min_tiles = int(os.environ.get("MPN_BN_ATOMIC_MIN_TILES", "0"))
-        self.bn_atomic_max_tiles = int(os.environ.get("MPN_BN_ATOMIC_MAX_TILES", str(1 << 30)))
+        self.bn_atomic_min_tiles = int(os.environ.get("MPN_BN_ATOMIC_MIN_TILES", "65"))
+        self.bn_atomic_max_tiles = int(os.environ.get("MPN_BN_ATOMIC_MAX_TILES", "1000"))
         self._bn_channels = None
 
     def side_stream(self, device):
@@ -307,16 +306,14 @@ class Engine(object):
                 return None
             if self._bn_channels is None:
                 self._bn_channels = sum(m.num_features for m in self.m.modules() if isinstance(m, torch.nn.BatchNorm2d))
-            if ctx.stat_acc is None or ctx.stat_acc_next + C * self.bn_atomic_copies * 2 > ctx.stat_acc.numel():
-                n = max(self._bn_channels, C) * self.bn_atomic_copies * 2
-                ctx.stat_acc = torch.empty(n, dtype=torch.int64, device=device)
-                call("mpn_fill_f32", ops.ptr(ctx.stat_acc), 0.0, n * 2, ops.stream_ptr())
+            if ctx.stat_acc is None or ctx.stat_acc_next + C > ctx.stat_acc.shape[0]:
+                ctx.stat_acc = torch.empty((max(self._bn_channels, C), 2), dtype=torch.int64, device=device)
+                call("mpn_fill_f32", ops.ptr(ctx.stat_acc), 0.0, ctx.stat_acc.numel() * 2, ops.stream_ptr())
                 ctx.stat_acc_next = 0
                 ctx.keep.append(ctx.stat_acc)
-            n = C * self.bn_atomic_copies * 2
-            a = ctx.stat_acc[ctx.stat_acc_next: ctx.stat_acc_next + n]
-            ctx.stat_acc_next += n
-            return a.view(self.bn_atomic_copies, C, 2) if self.bn_atomic_copies > 1 else a.view(C, 2)
+            a = ctx.stat_acc[ctx.stat_acc_next: ctx.stat_acc_next + C]
+            ctx.stat_acc_next += C
+            return a
         return take
 
     def conv(self, ctx, x, layer, act=0, res=None, res_mode=0, stats=False, out_f32=False, tag="", bn=None):

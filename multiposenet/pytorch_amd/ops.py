@@ -474,7 +474,7 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
             # atomic statistics (mpn.h: stats_atomic): every workgroup adds its tile's (sum, sum^2) to ONE pair of fixed-point
             # accumulators per channel; bn_act_acc derives the coefficients itself — no partial table, no finalize launch
             stats = StatAcc(acc, x.B * Ho * Wo)
-            p.stats, p.stats_atomic = acc.data_ptr(), (2 if acc.dim() == 3 else STAT_ATOMIC_MODE)
+            p.stats, p.stats_atomic = acc.data_ptr(), 1
         else:
             stats = torch.empty((tiles, Cout, 2), dtype=torch.float32, device=dev)
             p.stats = stats.data_ptr()
@@ -669,12 +669,8 @@ def fin_counters(device):
     return t
 
 
-STAT_ATOMIC_MODE = int(os.environ.get("MPN_BN_ATOMIC_MODE", "1"))      # 1: atomics after the tile's stores, 3: before them
-
-
 class StatAcc(object):
-    """Atomic batch statistics of one BatchNorm input: ``acc`` = int64 [C, 2] fixed-point totals, or [8, C, 2] per-XCD copies
-    (mpn.h: stats_atomic 1 / 2)."""
+    """Atomic batch statistics of one BatchNorm input: ``acc`` = int64 [C, 2] fixed-point totals (mpn.h: stats_atomic)."""
     __slots__ = ("acc", "count")
 
     def __init__(self, acc, count):
@@ -719,14 +715,13 @@ def bn_act(y, st, relu, res=None, needs_grad=False, tag="", want_mask=False):
 def bn_act_acc(y, sacc, gamma, beta, rm, rv, momentum, eps, relu, res=None, needs_grad=False, tag="", want_mask=False):
     """Training-mode z = act(bn(y) [+ res]) from atomic statistics (mpn.h: mpn_bn_act_acc_forward): coefficients, running
     statistics and the normalise pass in ONE launch.  Returns (z, BNState)."""
-    assert sacc.count == y.P and sacc.acc.shape[-2] == y.C and sacc.acc.is_contiguous()
-    copies = sacc.acc.shape[0] if sacc.acc.dim() == 3 else 1
+    assert sacc.count == y.P and tuple(sacc.acc.shape) == (y.C, 2) and sacc.acc.is_contiguous()
     st = BNState(y.C, y.t.device)
     z = Act(torch.empty_like(y.t), y.C, needs_grad, tag)
     if want_mask and relu:
         z.mask = torch.empty((y.P, y.Cs // (4 if y.t.dtype == torch.float32 else 8)), dtype=torch.uint8, device=y.t.device)
     call("mpn_bn_act_acc_forward", ptr(y.t), ptr(res.t) if res is not None else None, ptr(z.t), y.P, y.C, y.Cs, 1 if relu else 0,
-         dtype_code(y.t.dtype), ptr(z.mask), ptr(sacc.acc), copies, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), momentum, eps,
+         dtype_code(y.t.dtype), ptr(z.mask), ptr(sacc.acc), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), momentum, eps,
          ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), stream_ptr())
     return z, st
 

@@ -18,21 +18,19 @@ def _need_gpu():
     _lib.lib()
 
 
-def _acc_alloc(C, copies):
-    acc = torch.zeros((copies, C, 2) if copies > 1 else (C, 2), dtype=torch.int64, device="cuda")
+def _acc_alloc(C):
+    acc = torch.zeros((C, 2), dtype=torch.int64, device="cuda")
     return acc, (lambda tiles, c: acc)
 
 
 # ------------------------------------------------------------------------------------------------ atomic statistics
-@pytest.mark.parametrize("copies", [1, 8])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [(2, 30, 30, 64, 256, 1), (3, 17, 19, 128, 128, 3), (1, 40, 40, 256, 1024, 1), (2, 8, 8, 64, 64, 3), (8, 120, 120, 64, 64, 1)])
-def test_conv_atomic_statistics_equal_the_tile_table(dtype, case, copies):
+def test_conv_atomic_statistics_equal_the_tile_table(dtype, case):
     """fpn.py:28-34 in training mode.  The conv epilogue adds (sum, sum^2) of its tile to one pair of 64-bit fixed-point accumulators
     per channel (mpn.h: stats_atomic) instead of writing a [tiles][C][2] table: the totals must equal the table's column sums to the
     fixed-point resolution (2^-28 / 2^-20 per tile, rounded to nearest), be bit-identical from run to run (integer adds commute),
-    and leave the output tensor untouched.  copies = 8: one accumulator copy per XCD, workgroup-scope atomics (stats_atomic 2) — the
-    900-tile case spreads its workgroups over all eight XCDs, so a copy shared by two XCDs would show as a wrong total."""
+    and leave the output tensor untouched (the 900-tile case has every XCD adding to the same words)."""
     from multiposenet.pytorch_amd import ops
     B, H, W, Cin, Cout, k = case
     x = rnd(dtype, rng_normal(11, B, Cin, H, W))
@@ -41,12 +39,12 @@ def test_conv_atomic_statistics_equal_the_tile_table(dtype, case, copies):
     tiles = table.shape[0]
     runs = []
     for _ in range(3):
-        acc, alloc = _acc_alloc(Cout, copies)
+        acc, alloc = _acc_alloc(Cout)
         y1, sa = ops.conv_forward(to_act(x, dtype), w_krsc(w, dtype), Cout, k, k, 1, k // 2, want_stats=True, stat_acc=alloc)
         assert isinstance(sa, ops.StatAcc) and sa.count == B * H * W
         torch.cuda.synchronize()
         assert torch.equal(y1.t, y0.t), "the statistics mode changed the convolution output"
-        runs.append(acc.clone() if copies == 1 else acc.sum(0))
+        runs.append(acc.clone())
     assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), "atomic statistics differ from run to run"
     tot = table.double().sum(0).cpu()
     got1 = runs[0][:, 0].double().cpu() / 2.0 ** 28
@@ -56,10 +54,9 @@ def test_conv_atomic_statistics_equal_the_tile_table(dtype, case, copies):
     assert e1 <= tiles * 2.0 ** -29 + 1e-12 and e2 <= tiles * 2.0 ** -21 + 1e-12
 
 
-@pytest.mark.parametrize("copies", [1, 8])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("C", [64, 256, 1024, 2048])
-def test_bn_act_from_atomic_statistics_equals_finalize_plus_bn_act(dtype, C, copies):
+def test_bn_act_from_atomic_statistics_equals_finalize_plus_bn_act(dtype, C):
     """mpn_bn_act_acc_forward == mpn_bn_finalize_train + mpn_bn_act_forward (coefficients, running statistics, z, mask bits), and
     both == torch's F.batch_norm in training mode within the kernel tolerances of test_batchnorm_train_and_eval."""
     from multiposenet.pytorch_amd import ops
@@ -75,9 +72,6 @@ def test_bn_act_from_atomic_statistics_equals_finalize_plus_bn_act(dtype, C, cop
     s1, s2 = yv.sum((0, 2, 3)), (yv * yv).sum((0, 2, 3))
     table = torch.stack([s1, s2], 1).float().unsqueeze(0).contiguous().cuda()
     acc = torch.stack([torch.round(table[0, :, 0].double() * 2.0 ** 28), torch.round(table[0, :, 1].double() * 2.0 ** 20)], 1).to(torch.int64).contiguous()
-    if copies > 1:              # split the totals unevenly over the copies (some negative): the consumer must add them as integers
-        parts = [acc // 3, acc - acc // 3 + 12345, torch.full_like(acc, -12345)] + [torch.zeros_like(acc)] * (copies - 3)
-        acc = torch.stack(parts).contiguous()
     for relu, use_res in ((True, False), (True, True), (False, False)):
         rm, rv = rm0.clone(), rv0.clone()
         z = F.batch_norm(y.clone(), rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5)
@@ -118,8 +112,9 @@ def test_training_step_with_atomic_statistics_matches_the_finalize_launches_and_
     out = {}
     for mode in ("0", "1", "1"):
         m = get_model(50, torch.float32)
-        default = m._engine.bn_atomic
-        m._engine.bn_atomic = mode == "1"
+        eng = m._engine
+        default = (eng.bn_atomic, eng.bn_atomic_min_tiles, eng.bn_atomic_max_tiles)
+        eng.bn_atomic, eng.bn_atomic_min_tiles, eng.bn_atomic_max_tiles = mode == "1", 0, 1 << 30      # every BatchNorm layer, whatever its size
         for p in m.prn.parameters():
             p.requires_grad = False
         m.train()
@@ -129,7 +124,7 @@ def test_training_step_with_atomic_statistics_matches_the_finalize_launches_and_
         loss, _ = poseNet.build_loss(saved, "keypoint_subnet", heat, wgt)
         loss.backward()
         torch.cuda.synchronize()
-        m._engine.bn_atomic = default
+        eng.bn_atomic, eng.bn_atomic_min_tiles, eng.bn_atomic_max_tiles = default
         rs = torch.cat([v.flatten().float() for k, v in sorted(m.state_dict().items()) if "running_" in k])
         out.setdefault(mode, []).append((pred.detach().clone(), float(loss), m._arena.grad_flat.clone(), rs.clone()))
     (p0, l0, g0, r0), = out["0"]
