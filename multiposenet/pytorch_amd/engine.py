@@ -119,13 +119,13 @@ class Engine(object):
         # neutral (41.55 vs 41.67 ms in one call: the pass it removes costs what the extra epilogue load of eight MFMA-bound tower
         # launches costs, which also lose the lighter "plain" kernel): off by default
         self.fuse_relu_bwd = os.environ.get("MPN_FUSE_RELU_BWD", "0") != "0"
-        # training forward: the conv epilogue adds its tile statistics to per-channel 64-bit fixed-point accumulators with integer
-        # atomics (order-independent, deterministic) and bn_act derives the coefficients in its prologue: the finalize launch between
-        # conv and bn_act — 16 us of dependent kernel boundary per BatchNorm layer in a chain that has nothing beside it — is gone.
-        # The atomics are carried out at the memory side (~10 us per 30x30 layer even packed into whole lines), so the gain is a
-        # fraction of the 1.6 ms the launches cost: -0.2 ms/step for layers of 65 .. 1000 pixel tiles (30x30, 60x60), a LOSS beyond
-        # (120x120: 3600 tiles x C x 2 atomics, +0.4 ms) and below (<= 64 tiles: the in-launch finalize of ops.FIN_MAX_TILES is cheaper)
-        self.bn_atomic = os.environ.get("MPN_BN_ATOMIC_STATS", "1") != "0"
+        # training forward, OFF by default (measured neutral): the conv epilogue adds its tile statistics to per-channel 64-bit
+        # fixed-point accumulators with integer atomics (order-independent, deterministic) and bn_act derives the coefficients in its
+        # prologue, so the finalize launch between conv and bn_act — 16 us of dependent kernel boundary per BatchNorm layer, 1.6 ms a
+        # step by ablation — is gone.  But gfx950 carries every global atomic out at the memory side: even packed into whole lines
+        # and issued before the tile's stores the atomics cost what the launches cost (layers of 65 .. 1000 pixel tiles: 37.74 vs
+        # 37.75 ms/step; every layer: +0.3 .. +2.1 ms depending on the form — profiles/r04_bn_atomic_stats_ab.txt)
+        self.bn_atomic = os.environ.get("MPN_BN_ATOMIC_STATS", "0") != "0"
         self.bn_atomic_min_tiles = int(os.environ.get("MPN_BN_ATOMIC_MIN_TILES", "65"))
         self.bn_atomic_max_tiles = int(os.environ.get("MPN_BN_ATOMIC_MAX_TILES", "1000"))
         self._bn_channels = None
