@@ -208,6 +208,12 @@ typedef struct MpnWgradParams {
     int32_t kseg_shift[4];
     const void* kseg_x[4];
 } MpnWgradParams;
+/* tools/kloop_profile.py only: device buffer [workgroups][4 waves][8] of uint64 that the following 128 x 128-tile bf16 weight-gradient
+ * launches fill with per-wave s_memtime cycle sums of their k-loop phases (own-DMA wait, barrier wait, DMA issue, fragment reads +
+ * MFMA issue, whole loop, epilogue, k-steps, start stamp); NULL = off (production kernels contain none of this) */
+int mpn_debug_wgrad_prof(void* buf);
+/* the same for the 128-row bf16 forward / input-gradient launches (conv_igemm_kernel, conv_igemm_s3_kernel); synchronises the device */
+int mpn_debug_igemm_prof(void* buf);
 
 int mpn_conv_wgrad_chunks(const MpnWgradParams* p);
 /* pyramid mode: chooses the slice length for the summed pixel count, writes p->chunks, p->seg_chunk0, p->seg_chunk_pixels;

@@ -88,6 +88,8 @@ SIGNATURES = {
     "mpn_conv_tile_rows": (_i, [_PC]),
     "mpn_conv_shared_tile": (_i, [_PC]),
     "mpn_conv_forward": (_i, [_PC, _vp]),
+    "mpn_debug_wgrad_prof": (_i, [_vp]),
+    "mpn_debug_igemm_prof": (_i, [_vp]),
     "mpn_conv_wgrad_chunks": (_i, [_PW]),
     "mpn_conv_wgrad_seg_plan": (_i, [_PW]),
     "mpn_conv_wgrad": (_i, [_PW, _vp]),

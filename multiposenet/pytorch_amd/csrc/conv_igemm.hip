@@ -24,6 +24,7 @@
 // tile of a kernel row lands once for its three taps (the k-loop is bound by operand delivery, not by MFMA issue).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -619,6 +620,26 @@ __device__ __forceinline__ void lds_dma16(unsigned voff, i32x4_t rsrc, unsigned 
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
+// tools/kloop_profile.py only (PROF instantiations; production kernels compile none of it): per-wave s_memtime cycle sums of the
+// k-loop phases — own-DMA wait, barrier wait, DMA issue, fragment reads + MFMA issue — written to [workgroup][wave][8] at the end
+__device__ unsigned long long* d_igemm_prof = nullptr;
+struct KProf {
+    unsigned long long pt[4] = {0ull, 0ull, 0ull, 0ull}, t[4], start;
+    __device__ __forceinline__ void begin() { start = __builtin_readcyclecounter(); }
+    template <int I> __device__ __forceinline__ void mark() { t[I] = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void step() {
+        const unsigned long long e = __builtin_readcyclecounter();
+        pt[0] += t[1] - t[0]; pt[1] += t[2] - t[1]; pt[2] += t[3] - t[2]; pt[3] += e - t[3];
+    }
+    __device__ __forceinline__ void finish(int nsteps, unsigned long long loop_end) {
+        if ((threadIdx.x & 63) == 0 && d_igemm_prof) {
+            unsigned long long* d = d_igemm_prof + ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+            d[0] = pt[0]; d[1] = pt[1]; d[2] = pt[2]; d[3] = pt[3];
+            d[4] = loop_end - start; d[5] = __builtin_readcyclecounter() - loop_end; d[6] = (unsigned long long)nsteps; d[7] = start;
+        }
+    }
+};
+
 // Main kernel.  Operand tiles travel HBM -> LDS by DMA into a 3-deep ring, two k-steps ahead of the MFMAs; no
 // staging registers, no ds_write pass.  A tile row is one 64-byte k-chunk of a cout (A) or of a gathered pixel (B);
 // rows are stored back to back (the DMA destination is lane-linear) and the four 16-byte pieces of row `i` are
@@ -629,7 +650,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // Halo pixels, rows past Cout / past the last pixel carry an out-of-range offset and arrive as zeros.  The loads
 // are invisible to the compiler's waitcnt pass: completion is counted by hand (vmcnt(LPS) = everything but the
 // newest k-step has landed) and the barrier is the raw s_barrier, so the ring never drains inside the loop.
-template <typename T, int TC, int TP, bool OUTF32, bool GENERAL, bool EXT = false>
+template <typename T, int TC, int TP, bool OUTF32, bool GENERAL, bool EXT = false, bool PROF = false>
 __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_kernel(const MpnConvParams pk, const int dbg) {
     using C = ConvCfg<T, TC, TP>;
     __shared__ __attribute__((aligned(16))) unsigned char lds[C::NST * C::STAGE_BYTES];
@@ -757,23 +778,32 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_kernel(const
     };
     if (dbg & 32) return;                    // ablation: prologue only
 
+    KProf kp;
+    if (PROF) kp.begin();
     issue(0u);
     if (nsteps > 1) issue(1u);
     unsigned cur = 0u, nxt = 2u;
     for (int it = 0; it < nsteps; ++it) {
+        if (PROF) kp.mark<0>();
         if (it + 1 < nsteps) wait_vmcnt<C::LPS>(); else wait_vmcnt<0>();     // k-step `it` has landed (this wave's part)
+        if (PROF) kp.mark<1>();
         __builtin_amdgcn_s_barrier();                                          // ... everyone's; slot `nxt` is free again
+        if (PROF) kp.mark<2>();
         if (it + 2 < nsteps) issue(nxt);
+        if (PROF) kp.mark<3>();
         compute(cur);
+        if (PROF) kp.step();
         cur = (cur == C::NST - 1) ? 0u : cur + 1u;
         nxt = (nxt == C::NST - 1) ? 0u : nxt + 1u;
     }
+    const unsigned long long loop_end = PROF ? __builtin_readcyclecounter() : 0ull;
     __syncthreads();                          // the epilogue re-uses the ring as its staging area
 
     if (dbg & 16) { if (acc[0][0][0] == 123.456f) ((float*)p.y)[0] = 1.f; return; }   // ablation: no epilogue
     const int ntiles = (int)(gridDim.x / (unsigned)tilesC);       // pixel tiles of the launch (in-launch finalize)
     if (OUTF32) conv_epilogue<T, float, TC, TP, GENERAL, EXT>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
     else        conv_epilogue<T, T, TC, TP, GENERAL, EXT>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
+    if (PROF) kp.finish(nsteps, loop_end);
 }
 
 // 3x3 / stride 1 / pad 1 variant (forward and stride-1 dgrad), 16-bit types: the k-loop is bound by operand delivery (global -> LDS
@@ -784,7 +814,7 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_kernel(const
 // taps; the vertical border is a property of the row itself (every consumer of a row sits in the same output line) and stays a
 // DMA-time zero fill.  Per group: 3 weight tiles + 1 pixel tile instead of 3 + 3 (-31 % DMA bytes, -25 % DMA instructions).
 // k order: (r, channel chunk, s).  LDS: weight ring 3 x A_BYTES, pixel ring 2 x 12 KB (same total as the generic kernel).
-template <typename T, int TC, int TP, bool OUTF32, bool GENERAL, bool EXT = false>
+template <typename T, int TC, int TP, bool OUTF32, bool GENERAL, bool EXT = false, bool PROF = false>
 __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(const MpnConvParams pk, const int dbg) {
     using C = ConvCfg<T, TC, TP>;
     static_assert(sizeof(T) == 2 && TP == 128, "16-bit operands, 128-pixel tiles");
@@ -962,6 +992,8 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
     };
 
     // prologue: pixel tile of group 0, weight tiles of its first two taps
+    KProf kp;
+    if (PROF) kp.begin();
     issue_b(0u);
     issue_a(0u);
     issue_a(1u);
@@ -970,33 +1002,51 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
         const unsigned bcur = (unsigned)(g & 1);
         const bool last = g + 1 == groups;
         // tap 0: needs weights (g,0) and pixel tile g; younger in flight: weights (g,1)
+        if (PROF) kp.mark<0>();
         if (last) wait_vmcnt<0>(); else wait_vmcnt<LA>();
+        if (PROF) kp.mark<1>();
         __builtin_amdgcn_s_barrier();
+        if (PROF) kp.mark<2>();
         if (!last) issue_b(bcur ^ 1u);                            // pixel tile of the next group (its slot was last read one step ago)
         issue_a(anxt);                                            // weights (g,2)
+        if (PROF) kp.mark<3>();
         compute(acur, bcur, 0);
+        if (PROF) kp.step();
         acur = (acur == 2u) ? 0u : acur + 1u; anxt = (anxt == 2u) ? 0u : anxt + 1u;
         // tap 1: needs weights (g,1); younger: pixel tile g+1 and weights (g,2)
+        if (PROF) kp.mark<0>();
         if (last) wait_vmcnt<0>(); else wait_vmcnt<LB + LA>();
+        if (PROF) kp.mark<1>();
         __builtin_amdgcn_s_barrier();
+        if (PROF) kp.mark<2>();
         if (!last) issue_a(anxt);                                 // weights (g+1,0)
+        if (PROF) kp.mark<3>();
         compute(acur, bcur, 1);
+        if (PROF) kp.step();
         acur = (acur == 2u) ? 0u : acur + 1u; anxt = (anxt == 2u) ? 0u : anxt + 1u;
         // tap 2: needs weights (g,2); younger: weights (g+1,0)
+        if (PROF) kp.mark<0>();
         if (last) wait_vmcnt<0>(); else wait_vmcnt<LA>();
+        if (PROF) kp.mark<1>();
         __builtin_amdgcn_s_barrier();
+        if (PROF) kp.mark<2>();
         if (!last) issue_a(anxt);                                 // weights (g+1,1)
+        if (PROF) kp.mark<3>();
         compute(acur, bcur, 2);
+        if (PROF) kp.step();
         acur = (acur == 2u) ? 0u : acur + 1u; anxt = (anxt == 2u) ? 0u : anxt + 1u;
     }
+    const unsigned long long loop_end = PROF ? __builtin_readcyclecounter() : 0ull;
     __syncthreads();
 
     const int ntiles = (int)(gridDim.x / (unsigned)tilesC);
     if (OUTF32) conv_epilogue<T, float, TC, TP, GENERAL, EXT>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
     else        conv_epilogue<T, T, TC, TP, GENERAL, EXT>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
+    if (PROF) kp.finish(groups * 3, loop_end);
 }
 
 constexpr int kTP = 128;
+bool g_igemm_prof = false;          // tools/kloop_profile.py: route 128-row bf16 launches to the PROF instantiations
 
 // Block tile height (output channels).  The k-loop is bound by the DMA/LDS path, so the tallest tile that still
 // fills the chip wins: 256 rows (2 workgroups per CU) for long contractions with enough workgroups, else 128 rows
@@ -1023,6 +1073,13 @@ inline bool conv_uses_s3(const MpnConvParams& p, int tc) {
 
 template <typename T, bool OUTF32, bool GENERAL, bool EXT = false>
 int launch_conv_k(const MpnConvParams& p, int tc, long grid, int dbg, hipStream_t st) {
+    if constexpr (std::is_same<T, bf16_t>::value && !OUTF32 && !EXT) {
+        if (g_igemm_prof && tc == 128 && !p.fin_counters) {
+            if (conv_uses_s3(p, tc)) hipLaunchKernelGGL((conv_igemm_s3_kernel<T, 128, kTP, false, GENERAL, false, true>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+            else hipLaunchKernelGGL((conv_igemm_kernel<T, 128, kTP, false, GENERAL, false, true>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+            return mpn_launch_status();
+        }
+    }
     if constexpr (sizeof(T) == 2) {
         if (conv_uses_s3(p, tc)) {
             if (tc == 256) hipLaunchKernelGGL((conv_igemm_s3_kernel<T, 256, kTP, OUTF32, GENERAL, EXT>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
@@ -1064,6 +1121,12 @@ int launch_conv(const MpnConvParams& p, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int mpn_debug_igemm_prof(void* buf) {
+    g_igemm_prof = buf != nullptr;
+    unsigned long long* q = (unsigned long long*)buf;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(d_igemm_prof), &q, sizeof(q));
+}
 
 extern "C" int mpn_conv_stats_tiles(const MpnConvParams* p) {
     if (!p) return MPN_E_BADARG;

@@ -344,8 +344,16 @@ __device__ __forceinline__ const void* rfl_ptr(const void* q) {
 
 // SEG = pyramid mode (MpnWgradParams::nseg > 0): a separate instantiation, so the single-tensor kernels keep their register
 // allocation (the level lookup costs ~30 VGPRs of address arithmetic that the compiler no longer proves uniform)
-template <typename T, int TM, int TN, bool SEG>
-__device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, long chunk_pixels) {
+// PROF (tools/kloop_profile.py only): a separate instantiation that accumulates, per wave, the s_memtime cycles spent in the four phases
+// of a k-step — waiting for its own DMA (s_waitcnt vmcnt), waiting at the barrier, issuing the next k-step's DMA, fragment reads + MFMA
+// issue — and writes them to `prof` [workgroup][wave][8] at the end.  Production instantiations compile none of it.
+// What it showed (profiles/r04_kloop_phase_profile.txt): a k-step of a wave takes ~980 cycles — ~10 waiting for its DMA, ~45 at the
+// barrier, ~365 ISSUING four buffer_load ... lds (back-pressure of the CU's one texture path, 16 KB per k-step and workgroup), ~570 in
+// fragment reads + 16 MFMAs (256 cycles of matrix pipe).  Issuing the DMA between the MFMAs instead (built, measured, removed) moves
+// the stalls into the MFMA phase and leaves the k-step at ~920 cycles: the loop is bound by the texture path's ~45 B/clk, i.e. by the
+// tile's 64 FLOP per DMA byte, not by latency (the ring covers it) or by the wave's instruction order.
+template <typename T, int TM, int TN, bool SEG, bool PROF = false>
+__device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, long chunk_pixels, unsigned long long* prof = nullptr) {
     const bool ablate_stores = (chunk_pixels >> 62) & 1;     // MPN_WGRAD_ABLATE=2 (tools only): how much do the partial stores cost?
     chunk_pixels &= ~(1L << 62);
     constexpr int KP = 32, NST = 3;
@@ -496,18 +504,30 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, lo
     const int nsteps = span > 0 ? (int)((span + KP - 1) / KP) : 0;
     // steps past the slice end are still queued (their dY rows are out of range -> zeros, never consumed) so the
     // outstanding-load count is the same in every iteration
+    unsigned long long pt[4] = {0ull, 0ull, 0ull, 0ull};
+    const unsigned long long p_start = PROF ? __builtin_readcyclecounter() : 0ull;
     issue(0u);
     issue(1u);
     unsigned cur = 0u, nxt = 2u;
     for (int it = 0; it < nsteps; ++it) {
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if (PROF) t0 = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(QA + QB) : "memory");      // k-step `it` has landed (this wave's part)
+        if (PROF) t1 = __builtin_readcyclecounter();
         __builtin_amdgcn_s_barrier();                          // ... everyone's part; and slot `nxt` is no longer being read
+        if (PROF) t2 = __builtin_readcyclecounter();
         issue(nxt);
+        if (PROF) t3 = __builtin_readcyclecounter();
         compute(cur);
+        if (PROF) {
+            const unsigned long long t4 = __builtin_readcyclecounter();
+            pt[0] += t1 - t0; pt[1] += t2 - t1; pt[2] += t3 - t2; pt[3] += t4 - t3;
+        }
         cur = (cur == NST - 1) ? 0u : cur + 1u;
         nxt = (nxt == NST - 1) ? 0u : nxt + 1u;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long p_loop_end = PROF ? __builtin_readcyclecounter() : 0ull;
 
     const long NW = (long)p.Cout * taps * p.Cin;
     float* __restrict__ dst = (p.chunks > 1) ? (p.ws + (long)chunk * NW) : p.dw;
@@ -537,11 +557,21 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, lo
             if (!ablate_stores || v.x == 123.456f) *reinterpret_cast<float4*>(q) = v;
         }
     }
+    if (PROF && prof && lane == 0) {
+        const unsigned long long p_end = __builtin_readcyclecounter();
+        unsigned long long* d = prof + ((long)blockIdx.x * 4 + wave) * 8;
+        d[0] = pt[0]; d[1] = pt[1]; d[2] = pt[2]; d[3] = pt[3];
+        d[4] = p_loop_end - p_start; d[5] = p_end - p_loop_end; d[6] = (unsigned long long)nsteps; d[7] = p_start;
+    }
 }
 
 template <int TM, int TN>
 __global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_kernel(const MpnWgradParams p, long chunk_pixels) {
     conv_wgrad_dma_body<bf16_t, TM, TN, false>(p, chunk_pixels);
+}
+template <int TM, int TN>
+__global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_prof_kernel(const MpnWgradParams p, long chunk_pixels, unsigned long long* prof) {
+    conv_wgrad_dma_body<bf16_t, TM, TN, false, true>(p, chunk_pixels, prof);
 }
 template <int TM, int TN>
 __global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_f16_kernel(const MpnWgradParams p, long chunk_pixels) {
@@ -599,6 +629,8 @@ __global__ void reduce_partials_small_kernel(const float* __restrict__ ws, int c
         dst[i] = a;
     }
 }
+
+unsigned long long* g_wgrad_prof = nullptr;        // tools/kloop_profile.py: [workgroups][4 waves][8] cycle sums of the next 128x128 launches
 
 inline int pick_tile(int n) { return n > 64 ? 128 : (n > 32 ? 64 : 32); }
 
@@ -680,7 +712,9 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st, bool reduce = true) {
         else if (tm == 128) hipLaunchKernelGGL((KERNEL<128, 64>), g, blk, 0, st, p, chunk_pixels);                       \
         else if (tn == 128) hipLaunchKernelGGL((KERNEL<64, 128>), g, blk, 0, st, p, chunk_pixels);                       \
         else hipLaunchKernelGGL((KERNEL<64, 64>), g, blk, 0, st, p, chunk_pixels)
-        if (p.nseg > 0) {
+        if (g_wgrad_prof && p.nseg == 0 && p.dtype == MPN_BF16 && tm == 128 && tn == 128) {
+            hipLaunchKernelGGL((conv_wgrad_dma_prof_kernel<128, 128>), g, blk, 0, st, p, chunk_pixels, g_wgrad_prof);
+        } else if (p.nseg > 0) {
             if (p.dtype == MPN_F16) { MPN_WGRAD_DMA_LAUNCH(conv_wgrad_dma_seg_f16_kernel); }
             else { MPN_WGRAD_DMA_LAUNCH(conv_wgrad_dma_seg_kernel); }
         } else if (p.dtype == MPN_F16) { MPN_WGRAD_DMA_LAUNCH(conv_wgrad_dma_f16_kernel); }
@@ -704,6 +738,8 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st, bool reduce = true) {
 }
 
 }  // namespace
+
+extern "C" int mpn_debug_wgrad_prof(void* buf) { g_wgrad_prof = (unsigned long long*)buf; return 0; }
 
 extern "C" int mpn_conv_wgrad_seg_plan(MpnWgradParams* p) {
     if (!p || p->nseg <= 0 || p->nseg > 5) return MPN_E_BADARG;

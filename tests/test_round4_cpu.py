@@ -101,12 +101,12 @@ def _hot_kernels():
     hot = []
     for k in ("conv_igemm_kernel", "conv_igemm_s3_kernel"):
         for gen in (False, True):
-            hot.append((mangled(k, "t", 128, 128, False, gen, False), 3, 49152))     # 3 workgroups / CU (LDS: 3 x 48 KB)
-            hot.append((mangled(k, "t", 256, 128, False, gen, False), 2, 73728))     # 2 workgroups / CU
-            hot.append((mangled(k, "t", 64, 128, False, gen, False), 3, 36864))
+            hot.append((mangled(k, "t", 128, 128, False, gen, False, False), 3, 49152))     # 3 workgroups / CU (LDS: 3 x 48 KB)
+            hot.append((mangled(k, "t", 256, 128, False, gen, False, False), 2, 73728))     # 2 workgroups / CU
+            hot.append((mangled(k, "t", 64, 128, False, gen, False, False), 3, 36864))
     # conv2 through the virtual concatenation (extended epilogue, one launch per pass): 6 VGPRs / 27 SGPRs spilled in its prologue
     # and epilogue, none in the k-loop (checked in the ISA listing) — tolerated up to 8
-    hot.append((mangled("conv_igemm_s3_kernel", "t", 256, 128, False, True, True), 2, 73728, 8))
+    hot.append((mangled("conv_igemm_s3_kernel", "t", 256, 128, False, True, True, False), 2, 73728, 8))
     for tm, tn, lds in ((128, 128, 49152), (128, 64, 36864), (64, 128, 36864), (64, 64, 24576)):
         hot.append((mangled("conv_wgrad_dma_kernel", tm, tn), 3, lds))
     hot.append((mangled("conv_wgrad_dma_seg_kernel", 128, 128), 3, 49152))
