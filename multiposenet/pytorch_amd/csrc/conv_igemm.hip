@@ -453,9 +453,13 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
         unsigned rem = (pix < P ? pix : 0u) - b * HoWo;
         // The store loop runs in groups of G iterations: every global load of a group (residual, accumulate, the BatchNorm operands)
         // is in flight before the first result of the group is needed — one memory round trip per group instead of one per
-        // iteration (the accumulators are dead by now, their registers hold the loads).
+        // iteration (the accumulators are dead by now, their registers hold the loads).  Groups of 8 (round 4; 4 before): the loaded
+        // epilogues are HBM-latency bound — the phase profile shows 54 k cycles of epilogue against a 17 k-cycle k-loop in the conv1
+        // input-gradient launch that adds dz through the mask bits and collects the BatchNorm statistics (profiles/
+        // r04_kloop_phase_profile.txt) — so twice the loads in flight per wave: that launch 102.6 -> 96.6 us, step 37.93 -> 37.55 ms,
+        // and the 128-row kernel needs FEWER registers (one group = the whole pass: 152 instead of 166 VGPRs).
         constexpr int NIT = PASS_TILES * 16 / PPI;
-        constexpr int GMAX = 4;
+        constexpr int GMAX = 8;
         constexpr int G = NIT < GMAX ? NIT : GMAX;
         static_assert(NIT % G == 0, "store groups");
 #pragma unroll

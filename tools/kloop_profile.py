@@ -38,7 +38,7 @@ def report(tag, buf, nwg, us):
     ph = [t[:, :, k][live] / steps for k in range(4)]
     loop, epi = t[:, :, 4][live], t[:, :, 5][live]
     span = (t[:, :, 7][live] + loop + epi).max() - t[:, :, 7][live].min()
-    print("  %-6s %7.1f us | k-steps %3d | per k-step: wait %5.0f barr %5.0f issue %5.0f mma %5.0f = %5.0f cyc | loop %6.0f (+prologue) epilogue %6.0f cyc | "
+    print("  %-14s %7.1f us | k-steps %3d | per k-step: wait %5.0f barr %5.0f issue %5.0f mma %5.0f = %5.0f cyc | loop %6.0f (+prologue) epilogue %6.0f cyc | "
           "span %5.1f us, %d workgroups" % (tag, us, steps.mean(), ph[0].mean(), ph[1].mean(), ph[2].mean(), ph[3].mean(), sum(p.mean() for p in ph),
                                             loop.mean(), epi.mean(), span / CLK, nwg), flush=True)
 
@@ -72,6 +72,18 @@ def main():
             "dgrad": lambda: ops.conv_forward(dy, wt, Cin, k, k, 1, pad, mode=1, out_hw=(H, H), cin=Cout, out=dx),
             "wgrad": lambda: ops.conv_wgrad(x, dy, dw, Cout, k, k, 1, pad),
         }
+        if k == 1 and Cin == 1024:
+            # the most expensive shape of the step (22 launches x 77.6 us, r03): input gradient of a Bottleneck's conv1 with the deferred
+            # shortcut gradient (dz through the ReLU sign bits) and the BatchNorm-backward statistics of the block below in the epilogue
+            P, V = B * H * H, 8
+            dz = ops.Act(torch.randn(B, H, H, Cin, device=dev).to(dt), Cin)
+            by = ops.Act(torch.randn(B, H, H, Cin, device=dev).to(dt), Cin)
+            bz = ops.Act(torch.randn(B, H, H, Cin, device=dev).to(dt), Cin)
+            bz.mask = torch.randint(0, 256, (P, Cin // V), dtype=torch.uint8, device=dev)
+            st = ops.BNState(Cin, torch.device(dev))
+            st.mean.normal_(); st.invstd.uniform_(0.5, 1.5); st.scale.fill_(1.0); st.shift.zero_()
+            runs["dgrad+res+bnb"] = lambda: ops.conv_forward(dy, wt, Cin, k, k, 1, pad, mode=1, out_hw=(H, H), cin=Cout, out=dx,
+                                                              bnb=(by, bz, st, True), res=dz, res_mode=1, res_mask=bz.mask)
         print(name, flush=True)
         for tag, fn in runs.items():
             for _ in range(2):
