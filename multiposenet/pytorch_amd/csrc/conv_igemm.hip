@@ -459,7 +459,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
         // r04_kloop_phase_profile.txt) — so twice the loads in flight per wave: that launch 102.6 -> 96.6 us, step 37.93 -> 37.55 ms,
         // and the 128-row kernel needs FEWER registers (one group = the whole pass: 152 instead of 166 VGPRs).
         constexpr int NIT = PASS_TILES * 16 / PPI;
-        constexpr int GMAX = 8;
+        constexpr int GMAX = EXT ? 4 : 8;          // the extended epilogue carries three more load arrays per group: 8 would spill (70 VGPRs)
         constexpr int G = NIT < GMAX ? NIT : GMAX;
         static_assert(NIT % G == 0, "store groups");
 #pragma unroll
