@@ -64,11 +64,15 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and the gradient reducer even with one rank")
+    ap.add_argument("--shared-device-test", action="store_true",
+                    help="TEST SWITCH, NOT A MEASUREMENT: run the N ranks of --gpus N on ONE device over gloo (RCCL refuses two ranks on one "
+                         "GPU), so that the spawn -> rendezvous -> data-parallel step -> one-JSON-line path executes on a 1-GPU box; the line "
+                         "carries \"not_a_measurement\": true")
     return ap.parse_args()
 
 
 def synth(batch, size, device, seed):
-    from oracle import weightgen          # data generator only (deterministic Philox), not arithmetic
+    from multiposenet.pytorch_amd import synthetic as weightgen          # data generator only (deterministic Philox), not arithmetic
     img = torch.from_numpy(weightgen.gen_images(seed, batch, size, size))
     heat, wgt = weightgen.gen_keypoint_gt(seed, batch, size // 4, size // 4)
     anno = torch.from_numpy(weightgen.gen_boxes_gt(seed, batch, size, max_n=8))
@@ -76,7 +80,7 @@ def synth(batch, size, device, seed):
 
 
 def he_weights(model):
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = weightgen.gen_state_dict(shapes, seed=0, flavour="he", skip_prefixes=("prn.",))
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
@@ -102,7 +106,8 @@ def cpu_baseline_worker(args):
     """Runs in a subprocess (hard timeout in the parent): the oracle's torch-CPU restatement of the
     same step (fwd + both losses + bwd + Adam).  Bounded: a 160x160 calibration step decides whether
     the full 480x480 sample fits the time box; otherwise the calibration is reported, scaled by pixels."""
-    from oracle import posenet_oracle as po, weightgen
+    from oracle import posenet_oracle as po
+    from multiposenet.pytorch_amd import synthetic as weightgen
     cores = min(host_cores(), 64)
     torch.set_num_threads(cores)
     g = np.load(os.path.join(ROOT, "tests", "golden", "g0_keys.npz"))      # state_dict names/shapes of the reference
@@ -186,6 +191,8 @@ def spawn_ranks(args):
     torch.distributed.run, rendezvous on 127.0.0.1) — the same command line the driver uses for N > 1.  Never returns."""
     import socket
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if args.shared_device_test and ndev >= 1:
+        ndev = args.gpus                                    # every rank will use device 0 (gloo)
     if ndev < args.gpus:
         sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to run a smaller job under that label\n"
                          % (args.gpus, ndev))
@@ -222,6 +229,8 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if args.shared_device_test:
+        local = 0
     if torch.cuda.device_count() <= local:
         sys.stderr.write("bench.py: rank %d wants cuda:%d but only %d GPU(s) are visible\n" % (rank, local, torch.cuda.device_count()))
         sys.exit(3)
@@ -233,7 +242,10 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.shared_device_test:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -294,7 +306,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.shared_device_test else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(loss).all()
@@ -358,6 +370,9 @@ def main():
                                   "replay": "recorded launch list re-issued per step (replay.py)"}[args.launch]
                                  + ("" if gstep is None else ", %d replays" % gstep.replays)},
         }
+        if args.shared_device_test:
+            out["not_a_measurement"] = True
+            out["config"]["parallelism"] += " (TEST: %d ranks sharing one device over gloo — exercises the launch path, measures nothing)" % world
         out["ms_per_step_median_hipevent"] = round(median_ms, 3)
         out["ms_per_step_min_max_hipevent"] = [round(step_ms[0], 3), round(step_ms[-1], 3)]
         out["last_step_log"] = {k: round(float(v), 6) for k, v in last_log["log"].items()      # values exist, they were just

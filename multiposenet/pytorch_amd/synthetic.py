@@ -1,10 +1,10 @@
-"""Deterministic, repo-owned weight / input generator (TEST INFRASTRUCTURE).
+"""Deterministic synthetic inputs and weights: COCO-shaped batches for bench.py / the trainer smoke paths, and the shared starting
+point of every parity test.
 
-This file is part of ``oracle/``: it is test infrastructure, never part of the
-shipped product path.  It produces the *same* numbers in this container (where
-the reference is imported to make golden fixtures) and on the GPU box (where
-only the fixtures travel), so both sides of a parity test start from identical
-parameters without committing 100+ MB of weights.
+A data generator, no network arithmetic: the same numbers in the build container (where tests/golden/make_golden*.py feed them to
+the REAL reference to make the fixtures) and on the GPU box (where only the fixtures travel), so both sides of a parity test start
+from identical parameters without committing 100+ MB of weights.  (Lived with the test infrastructure until round 3; bench.py and
+the product's own smoke paths must stand on the package alone, so it moved here: the checkers import it, never the other way round.)
 
 Generator: numpy ``Philox`` keyed by SHA-256(seed, tensor name).  Philox is a
 counter-based bit generator whose stream is specified (Random123) and stable

@@ -26,7 +26,7 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from multiposenet.pytorch_amd import ddp
     from multiposenet.pytorch_amd.network.posenet import poseNet
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
 
     torch.manual_seed(100 + rank)           # ranks start different: attach() must broadcast rank 0's parameters
     m = poseNet(50, compute_dtype=torch.float32).cuda()

@@ -8,7 +8,7 @@ Import recipe: the reference targets torch 0.4 / CUDA, so
   * lib.nms.pth_nms is pre-seeded (torch.utils.ffi no longer exists) with the C oracle's gpu-mode NMS,
   * Tensor.cuda / Module.cuda become no-ops (this container has no GPU),
   * bool.__rsub__ is patched for the dead statement at network/losses.py:124.
-Weights/inputs come from oracle/weightgen.py so the GPU box can regenerate the identical tensors.
+Weights/inputs come from multiposenet/pytorch_amd/synthetic.py so the GPU box can regenerate the identical tensors.
 """
 import hashlib
 import os
@@ -27,7 +27,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from oracle import weightgen, nms_oracle
+from oracle import nms_oracle
+from multiposenet.pytorch_amd import synthetic as weightgen
 
 torch.set_num_threads(8)
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """g13_prn_process.npz: outputs of the REAL ``Tester.prn_process`` (evaluate/tester.py:333-513) on seeded peak / box sets,
-with the REAL reference ``poseNet.prn`` (seeded weights from oracle/weightgen.py) as the model.
+with the REAL reference ``poseNet.prn`` (seeded weights from multiposenet/pytorch_amd/synthetic.py) as the model.
 
 Build container only (needs /root/reference).  Shims: cv2 / pycocotools are never touched by prn_process and are stubbed so
 that evaluate/tester.py imports; ``skimage.filters.gaussian`` (absent here) is the scipy restatement that
@@ -20,7 +20,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from oracle import prn_assign_oracle, weightgen
+from oracle import prn_assign_oracle
+from multiposenet.pytorch_amd import synthetic as weightgen
 
 
 def stub(name, **attrs):

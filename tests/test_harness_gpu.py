@@ -42,7 +42,7 @@ class _State(object):
 
 
 def _loader(n, B, S, seed):
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     out = []
     for i in range(n):
         img = t(weightgen.gen_images(seed + i, B, S, S))

@@ -44,7 +44,7 @@ def get_model(layers, dtype):
 
 
 def load_he(model, seed=0):
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = weightgen.gen_state_dict(shapes, seed=seed, flavour="he", skip_prefixes=("prn.",))
     missing = model.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
@@ -65,7 +65,7 @@ def close(name, got, ref, atol, rel_l2):
 
 @pytest.mark.parametrize("layers", [50, 101])
 def test_forward_matches_reference_golden_fp32(layers):
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     g = gold("g2_forward_r%d.npz" % layers)
     model = get_model(layers, torch.float32)
     cases = [("eval", 2, 64, 64), ("eval", 2, 128, 128), ("train", 2, 128, 128)]
@@ -138,7 +138,7 @@ def _grad_check(model, g, tag, rel=5e-3):
 
 def test_losses_and_gradients_match_reference_golden_fp32():
     from multiposenet.pytorch_amd.network.posenet import poseNet
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     g = gold("g3_losses_r50.npz")
     b, s = 2, 128
     img = t(weightgen.gen_images(2, b, s, s)).cuda()
@@ -185,7 +185,7 @@ def test_three_adam_steps_match_reference_golden_fp32():
     """cfg-1 shapes (R50 keypoint 256^2 B2): loss trajectory + updated params after 3 Adam steps."""
     from multiposenet.pytorch_amd.network.posenet import poseNet
     from multiposenet.pytorch_amd.optim import FusedAdam
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     g = gold("g8_steps_r50.npz")
     img = t(weightgen.gen_images(8, 2, 256, 256)).cuda()
     heat, wgt = weightgen.gen_keypoint_gt(8, 2, 64, 64)
@@ -227,7 +227,7 @@ def test_three_adam_steps_match_reference_golden_fp32():
 
 
 def test_bf16_tracks_fp32():
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     img = t(weightgen.gen_images(1, 2, 128, 128)).cuda()
     g = gold("g2_forward_r50.npz")
     m = get_model(50, torch.bfloat16)
@@ -248,7 +248,7 @@ def test_bf16_tracks_fp32():
 def test_full_size_batch_independence_and_determinism():
     """BASELINE full size (R101, 480x480): size-independent properties — in eval mode an image's
     outputs do not depend on its batch neighbours (bit-exact), and two runs are bit-identical."""
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     m = get_model(101, torch.bfloat16)
     m.eval()
     img = t(weightgen.gen_images(3, 4, 480, 480)).cuda()
@@ -270,7 +270,8 @@ def test_prn_forward_loss_and_training_gradients():
     """A14: PRN eval forward + BCE loss vs the reference golden (g7), gradients vs the CPU oracle (dropout
     off), and dropout semantics (keep rate, 1/(1-p) scaling, same mask in backward)."""
     from multiposenet.pytorch_amd.network.posenet import poseNet
-    from oracle import posenet_oracle as po, weightgen
+    from oracle import posenet_oracle as po
+    from multiposenet.pytorch_amd import synthetic as weightgen
     g = gold("g7_prn.npz")
     model = get_model(50, torch.float32)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if k.startswith("prn.")}
@@ -316,7 +317,7 @@ def test_prn_forward_loss_and_training_gradients():
 def test_entire_net_all_images_equals_per_image_runs():
     """cfg5-style inference: per-image threshold + NMS for a whole batch; entry b must equal the reference
     semantics (image-0-only path) applied to image b alone — box index lists bit-exact, values identical."""
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     model = get_model(50, torch.float32)
     model.eval()
     img = t(weightgen.gen_images(11, 3, 128, 96)).cuda()
@@ -335,7 +336,7 @@ def test_training_step_is_deterministic_and_stream_overlap_changes_nothing():
     re-used too early would show up as run-to-run differences.  Size-independent property at a mid size (R101, 256x256,
     8 images, bf16, train-mode BN): the whole gradient arena and the loss are bit-identical across repeated steps from
     the same state, and identical to the serial schedule (side stream off)."""
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     from multiposenet.pytorch_amd.network.posenet import poseNet
     m = get_model(101, torch.bfloat16)
     m.train()
@@ -377,7 +378,7 @@ def test_loss_log_is_plain_floats_by_default_and_lazy_on_request():
     lazy proxies are numbers.Real, carry the same values, and behave like floats in the arithmetic/formatting the
     reference trainer applies (trainer.py:324-343)."""
     import numbers
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     from multiposenet.pytorch_amd.network import losses
     from multiposenet.pytorch_amd.network.posenet import poseNet
     m = get_model(50, torch.float32)
@@ -411,7 +412,7 @@ def test_cfg4_large_resolution_training_step_properties():
     """SURVEY 8d cfg4 shape class (R101 full posenet, 800x800, the upsample/concat stress): a train step at the full
     resolution (2 images) runs through every tile variant (256-row igemm tiles, sliced wgrad at 200x200), gives finite
     losses/gradients, and is bit-reproducible."""
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     from multiposenet.pytorch_amd.network.posenet import poseNet
     m = get_model(101, torch.bfloat16)
     m.train()
@@ -439,7 +440,7 @@ def test_cfg4_large_resolution_training_step_properties():
 def test_cfg5_inference_640_all_images_properties():
     """SURVEY 8d cfg5 shape class (R101 'both' inference at 640x640, A = 76 725 anchors): whole-batch inference equals
     the per-image reference semantics, boxes are inside the image, scores sorted and above the 0.05 threshold."""
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     m = get_model(101, torch.bfloat16)
     m.eval()
     img = t(weightgen.gen_images(31, 4, 640, 640)).cuda()

@@ -11,7 +11,8 @@ import pytest
 import torch
 
 from helpers import gold
-from oracle import nms_oracle, posenet_oracle as po, weightgen
+from oracle import nms_oracle, posenet_oracle as po
+from multiposenet.pytorch_amd import synthetic as weightgen
 
 torch.set_num_threads(8)
 

@@ -12,7 +12,7 @@ from helpers import gold
 
 
 def _prn_weights(model_or_shapes):
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     shapes = model_or_shapes if isinstance(model_or_shapes, dict) else {k: tuple(v.shape) for k, v in model_or_shapes.state_dict().items() if k.startswith("prn.")}
     return weightgen.gen_state_dict(shapes, seed=3, flavour="he", skip_prefixes=())
 

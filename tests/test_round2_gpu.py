@@ -27,7 +27,7 @@ def _need_gpu():
 def test_f16_forward_against_reference_goldens():
     """dtype code 2 (v_mfma_f32_16x16x32_f16, fp32 accumulate): heat-maps and detection outputs of the REAL reference
     (fixtures g2) within fp16 bounds — rel-L2 <= 5e-3 (10-bit mantissa; bf16's gate is 3e-2)."""
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     for layers in (50, 101):
         g = gold("g2_forward_r%d.npz" % layers)
         model = get_model(layers, torch.float16)
@@ -116,7 +116,7 @@ def test_cfg5_640_batch64_f16_all_images():
     the FULL size: shapes, boxes inside the image, scores sorted and above 0.05, three sampled images bit-identical to
     running them alone (the reference semantics, posenet.py:236-285), and exactly two host read-backs for the whole
     batch in the detection post-processing (none per image)."""
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     m = get_model(101, torch.float16)
     m.eval()
     B, S = 64, 640
@@ -157,7 +157,7 @@ def test_cfg5_640_batch64_f16_all_images():
 
 # ------------------------------------------------------------------------------------------------ hipGraph step + Adam state
 def _train_setup(layers, dtype, B, S, seed=50):
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     m = get_model(layers, dtype)
     for p in m.prn.parameters():
         p.requires_grad = False
@@ -522,7 +522,7 @@ def test_folded_batchnorm_inference_equals_the_separate_passes(dtype):
     """Inference with frozen statistics folds BatchNorm (+ReLU, + the residual add of a Bottleneck, fpn.py:28-34) into the
     conv epilogue (act code 3).  Same network, fold on / off: fp32 agrees to rounding (the fold skips one rounding of y),
     fp16 within its own precision."""
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     m = get_model(101, dtype)
     m.eval()
     img = t(weightgen.gen_images(160, 2, 192, 160)).cuda()

@@ -28,7 +28,8 @@ def test_cfg2_r50_keypoint_480_batch16_fp32_full_size():
     on a batch-2 slice of the same inputs the fp32 loss and every logged per-level loss equal the CPU oracle's within 2e-4
     relative, the heat-maps within the north-star 1e-3 abs."""
     from multiposenet.pytorch_amd.network.posenet import poseNet
-    from oracle import posenet_oracle as po, weightgen
+    from oracle import posenet_oracle as po
+    from multiposenet.pytorch_amd import synthetic as weightgen
     B, S = 16, 480
     m = get_model(50, torch.float32)
     for p in m.prn.parameters():
@@ -102,7 +103,7 @@ def test_trainer_uses_the_recorded_step_and_tester_val_matches_a_hand_loop(tmp_p
     from multiposenet.pytorch_amd.network.posenet import poseNet
     from multiposenet.pytorch_amd.training.batch_processor import batch_processor, train_step
     from multiposenet.pytorch_amd.training.trainer import Trainer, TrainParams
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     B, S = 2, 64
 
     def loader(n, seed):
@@ -263,7 +264,8 @@ def test_bf16_bottlenecks_against_an_oracle_that_rounds_where_the_kernels_round(
     these by far more."""
     from multiposenet.pytorch_amd import ops
     from multiposenet.pytorch_amd.engine import Ctx
-    from oracle import posenet_oracle as po, weightgen
+    from oracle import posenet_oracle as po
+    from multiposenet.pytorch_amd import synthetic as weightgen
     import torch.nn.functional as F
     B, S = 4, 128
     m = get_model(50, torch.bfloat16)
@@ -338,7 +340,8 @@ def test_bf16_training_step_sits_closer_to_the_rounding_oracle_than_to_fp32():
     but the HIP result must be CLOSER to (b) than to (a) — heat-maps and the typical parameter gradient — and the loss must agree
     with (b) to 1e-3."""
     from multiposenet.pytorch_amd.network.posenet import poseNet
-    from oracle import posenet_oracle as po, weightgen
+    from oracle import posenet_oracle as po
+    from multiposenet.pytorch_amd import synthetic as weightgen
     B, S = 4, 128
     m = get_model(50, torch.bfloat16)
     sd_np = load_he(m)
@@ -394,7 +397,7 @@ def test_relu_mask_bits_replace_z_in_both_backward_passes(dtype):
     and off; the bits themselves equal (z > 0) element for element."""
     from multiposenet.pytorch_amd import ops
     from multiposenet.pytorch_amd.network.posenet import poseNet
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     # kernel level
     B, H, W, C = 2, 9, 7, 64
     g = torch.Generator().manual_seed(5)
@@ -447,7 +450,7 @@ def test_virtual_concat_equals_the_materialised_concatenation(dtype):
     at kernel level on odd sizes, and for a whole training step (loss, every gradient)."""
     from multiposenet.pytorch_amd import ops
     from multiposenet.pytorch_amd.network.posenet import poseNet
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     dev = "cuda"
     g = torch.Generator().manual_seed(11)
     for (B, H, W) in ((2, 24, 40), (1, 8, 8), (3, 16, 24)):
@@ -510,7 +513,7 @@ def test_relu_backward_in_the_producing_dgrad_epilogue(dtype, pyramid):
     pass.  Same predicate on the same values: loss and every gradient of a `train_both` step bit-identical with the fusion on and
     off, for the one-launch-per-pyramid towers and for the per-level launches."""
     from multiposenet.pytorch_amd.network.posenet import poseNet
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     m = get_model(50, dtype)
     for p in m.prn.parameters():
         p.requires_grad = False
@@ -552,7 +555,7 @@ def test_cfg5_chain_batch64_f16_equals_per_image_inference():
     result dicts of six sampled images equal `Tester.infer_image` run on each alone (the reference semantics, tester.py:194-245) —
     boxes, scores and all 51 keypoint numbers."""
     from multiposenet.pytorch_amd.evaluate.tester import Tester, TestParams
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     m = get_model(101, torch.float16)
     sd = weightgen.gen_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items() if k.startswith("prn.")}, seed=3, flavour="he")
     m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)

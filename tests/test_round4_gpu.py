@@ -105,7 +105,7 @@ def test_training_step_with_atomic_statistics_matches_the_finalize_launches_and_
     noise, and two runs of the atomic path are bit-identical (integer atomics commute; the reference's own cuDNN statistics are not)."""
     from test_model_gpu import get_model, t
     from multiposenet.pytorch_amd.network.posenet import poseNet
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     B, S = 2, 128
     img = t(weightgen.gen_images(410, B, S, S)).cuda()
     heat, wgt = (t(a).cuda() for a in weightgen.gen_keypoint_gt(411, B, S // 4, S // 4))
@@ -219,3 +219,31 @@ def test_tta_driver_matches_the_real_reference_tester(tmp_path):
         assert r["score"] == q["score"] and np.abs(np.array(r["bbox"]) - np.array(q["bbox"])).max() <= 1e-3
     report("TTA driver vs the real Tester (2 images, 5 scales x flip): heat %.2e, average %.2e, boxes %.2e abs; %d joints, %d coordinates off by one pixel"
            % (worst["heat"], worst["avg"], worst["box"], sum(len(a[0]) for a in prn_args), moved))
+
+
+# ------------------------------------------------------------------------------------------------ bench.py spawn path
+def test_bench_spawn_path_runs_two_ranks_to_one_json_line():
+    """`python bench.py --gpus 2` starts its own ranks (spawn_ranks -> torch.distributed.run -> rendezvous on 127.0.0.1 -> the
+    data-parallel recorded step with the gradient reducer attached -> max-over-ranks timing -> ONE JSON line from rank 0).  Only
+    the two failure exits of that path had ever executed (fewer devices than ranks; launcher / flag mismatch: test_round3_cpu.py).
+    RCCL refuses two ranks on one GPU, so the loudly-labelled test switch --shared-device-test puts both ranks on device 0 over
+    gloo: exactly one stdout line, n_gpus 2, global batch = 2 x per-GPU batch, "not_a_measurement", and no cpu_baseline."""
+    import json
+    import subprocess
+    import sys
+    from helpers import ROOT
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--shared-device-test",
+           "--layers", "50", "--size", "256", "--batch", "4", "--no-kernel-events"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert res.returncode == 0, "bench.py --gpus 2 failed (rc %d):\n%s" % (res.returncode, res.stderr[-3000:])
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, "stdout must carry exactly one line, got %d:\n%s" % (len(lines), res.stdout[-2000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["not_a_measurement"] is True
+    assert out["config"]["global_batch"] == 8 and out["config"]["parallelism"].startswith("dp2")
+    assert "cpu_baseline" not in out and out["value"] > 0 and out["scaling"] == "weak"
+    report("bench.py --gpus 2 --shared-device-test: spawn -> rendezvous -> 3 data-parallel steps -> one JSON line (%.1f img/s on one shared device, not a measurement)"
+           % out["value"])

@@ -2,7 +2,8 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-from oracle import weightgen, posenet_oracle as po
+from oracle import posenet_oracle as po
+from multiposenet.pytorch_amd import synthetic as weightgen
 from multiposenet.pytorch_amd.network.posenet import poseNet
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x))
 b, s = 2, 128

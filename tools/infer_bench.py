@@ -27,7 +27,7 @@ def main():
     from multiposenet.pytorch_amd.evaluate.prn_process import prn_assign_arrays, prn_process_batch
     from multiposenet.pytorch_amd.network.joint_utils import NMS_batch, NMS_batch_arrays, body_peaks_flat
     from multiposenet.pytorch_amd.network.posenet import poseNet
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     import bench
     torch.cuda.set_device(0)
     dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]

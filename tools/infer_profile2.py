@@ -6,7 +6,7 @@ import numpy as np, torch
 from multiposenet.pytorch_amd.evaluate import prn_process as pp
 from multiposenet.pytorch_amd.network.joint_utils import NMS_batch_arrays, body_peaks_flat
 from multiposenet.pytorch_amd.network.posenet import poseNet
-from oracle import weightgen
+from multiposenet.pytorch_amd import synthetic as weightgen
 import bench
 torch.cuda.set_device(0)
 B, S = 64, 640

@@ -23,7 +23,7 @@ def main():
     args = ap.parse_args()
     from multiposenet.pytorch_amd.engine import Ctx
     from multiposenet.pytorch_amd.network.posenet import poseNet
-    from oracle import weightgen
+    from multiposenet.pytorch_amd import synthetic as weightgen
     torch.cuda.set_device(0)
     m = poseNet(args.layers, compute_dtype=torch.float32).cuda()
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
