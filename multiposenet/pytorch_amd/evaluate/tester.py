@@ -127,10 +127,23 @@ class Tester(object):
         ``batch_processor`` -> forward -> ``build_loss``; a log block every ``print_freq`` batches.  The reference only logs the
         result; here ``(mean, std)`` of the per-batch losses is returned as well.  Log values are fetched asynchronously
         (losses.LazyFloat) and read when a block is printed, so the loop never waits for the device in between."""
+        from ..network import losses
         from ..training.trainer import LogBook, RunningStat, Stopwatch, _scalar_proxy
         if self.val_data is None or self.batch_processor is None:
             raise ValueError('Tester.val() needs the val_data and batch_processor given to the constructor')
+        was_training = self.model.training
+        bn_modes = [(m, m.training) for m in self.model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
         self.model.eval()
+        was_lazy = losses.set_lazy_log(True)          # build_loss's log values: asynchronous proxies, read when a block is printed
+        try:
+            return self._val_loop(LogBook, RunningStat, Stopwatch, _scalar_proxy)
+        finally:
+            losses.set_lazy_log(was_lazy)
+            self.model.train(was_training)            # the modes the caller had (the reference leaves the model in eval mode; a
+            for m, mode in bn_modes:                  # Trainer calling val() between epochs must get its BatchNorm modes back)
+                m.train(mode)
+
+    def _val_loop(self, LogBook, RunningStat, Stopwatch, _scalar_proxy):
         book, seen = LogBook(), RunningStat()
         batch_timer, data_timer = Stopwatch(), Stopwatch()
         logger.info('Val on validation set...')
@@ -237,14 +250,16 @@ class Tester(object):
             peaks_xy = peaks_xy * np.repeat(sc, per_img)[:, None]                             # get_joint_list: peaks * scale
             nmax = boxes.shape[1]
             if nmax:
-                ok = (scores > 0.5) & (torch.arange(nmax, device=self.dev)[None, :] < torch.tensor(kept, device=self.dev)[:, None])
-                ok_h, boxes_h = ok.cpu().numpy(), boxes.cpu().numpy()
+                # score > 0.5 among the kept rows (the single class is class 0 = person: forward_all_images_padded refuses anything else,
+                # so the reference's `classification == 0` filter, tester.py:232, holds by construction); masks built on the host from the
+                # two arrays that travel anyway
+                scores_h, boxes_h = scores.cpu().numpy(), boxes.cpu().numpy()
+                ok_h = (scores_h > 0.5) & (np.arange(nmax)[None, :] < np.asarray(kept)[:, None])
             else:
                 ok_h, boxes_h = np.zeros((len(idx), 0), dtype=bool), np.zeros((len(idx), 0, 4), dtype=np.float32)
             # boxes * scale in float32 like the reference's numpy expression (tester.py:228-234), image-major
             b4 = (boxes_h[ok_h] * np.repeat(sc, ok_h.sum(1))[:, None].astype(np.float32)).astype(np.float64)
             start = np.concatenate([[0], np.cumsum(ok_h.sum(1))]).astype(np.int32)
-            xyxy = b4.copy()
             b4[:, 2:] -= b4[:, :2]
             kp = prn_assign_arrays(self.model, peaks_xy, joint_off, b4, start, in_thres=self.params.in_thres)
             for li, i in enumerate(idx):

@@ -200,9 +200,10 @@ LAZY_LOG = os.environ.get("MPN_LAZY_LOG", "0") == "1"
 def set_lazy_log(on=True):
     """Opt in to asynchronous log values (LazyFloat).  Off by default: build_*_loss then return plain Python floats
     exactly like the reference (whose trainer tests ``isinstance(v, (int, float))``, trainer.py:39,324) at the price of
-    one host sync between forward and backward (about 5 % of the step at 700 images/s)."""
+    one host sync between forward and backward (about 5 % of the step at 700 images/s).  Returns the previous setting."""
     global LAZY_LOG
-    LAZY_LOG = bool(on)
+    was, LAZY_LOG = LAZY_LOG, bool(on)
+    return was
 
 
 class _Deferred(object):

@@ -338,6 +338,11 @@ class poseNet(nn.Module):
         predict_keypoint, _ = eng.keypoint_head(ctx, kp, False)
         classification, regression = eng.detection_head(ctx, det)
         self._finish_forward(ctx)
+        if classification.shape[-1] != 1:
+            # the padded batch path has no class column: with several classes the arg-max class (posenet.py:283) would have to travel
+            # with every detection — use forward_all_images, which carries it
+            raise MpnError("forward_all_images_padded serves the single-class detector (classificationModel num_classes = 1), "
+                                "got %d classes" % classification.shape[-1])
         transformed_anchors = decode_and_clip(self.anchors(img_batch), regression, img_batch)
         boxes, scores, kept = ops.detect_batched(transformed_anchors, classification.reshape(classification.shape[0], -1), 0.05, 0.5, padded=True,
                                                  pre_nms_top_n=pre_nms_top_n)

@@ -44,15 +44,24 @@ class _Entry(object):
 
 
 class ReplayedTrainStep(object):
-    def __init__(self, model, optimizer, eager_steps=1, fused_mse=None):
+    def __init__(self, model, optimizer, eager_steps=1, fused_mse=None, max_entries=None, anno_bucket=8):
         self.model = model
         self.opt = optimizer
         # heat-map loss + gradients in one launch over the internal tensors (MPN_FUSED_MSE=0: the API path's kernel chain)
         self.fused_mse = (os.environ.get("MPN_FUSED_MSE", "1") != "0") if fused_mse is None else bool(fused_mse)
         self.eager_steps = max(1, int(eager_steps))       # steps that fill host-side caches (anchors, transpose table, Adam state)
-        self._entries = {}
+        # One recording per input signature, each owning a MemPool with a whole step's activations (GBs at the headline size).  The
+        # reference's bbox_collater pads annotations to the per-batch maximum, so detection training sees a new signature for nearly
+        # every distinct max_num_annots: the cache is an LRU of `max_entries` recordings (the evicted one's pool is released), and
+        # annotation tensors are padded with -1 rows (FocalLoss drops them, losses.py:47) to a multiple of `anno_bucket` rows before
+        # they become part of the key, which folds most of those signatures into a few
+        self.max_entries = max(1, int(os.environ.get("MPN_REPLAY_MAX_ENTRIES", "4") if max_entries is None else max_entries))
+        self.anno_bucket = max(1, int(anno_bucket))
+        self._entries = OrderedDict()
         self._seen = {}
+        self._warned = set()
         self.replays = 0
+        self.evictions = 0
 
     # ------------------------------------------------------------------ the autograd-free step body
     def _body(self, img, subnet, tensors):
@@ -141,17 +150,23 @@ class ReplayedTrainStep(object):
             from .training.batch_processor import train_step
             return train_step(self.model, self.opt, inputs, gts)
         ops.check_device(img)
-        # The recorded launches read the input tensors IN PLACE; a conversion (.float() / .contiguous()) inside the body would be
-        # a torch op that is not on the list, and replays would keep reading the first batch's converted copy.
-        for name, tsr in [("image batch", img)] + [("target %d" % i, g) for i, g in enumerate(tensors)]:
-            if tsr.dtype != torch.float32 or not tsr.is_contiguous():
-                raise _lib.MpnError("recorded train step: %s must be a contiguous float32 tensor (got %s, contiguous=%s); convert it in "
-                                    "the data pipeline or use training.batch_processor.train_step" % (name, tsr.dtype, tsr.is_contiguous()))
+        # The recorded launches read the input tensors IN PLACE; a conversion inside the body would be a torch op that is not on the
+        # list, and replays would keep reading the first batch's converted copy.  So inputs the eager path would convert (float64
+        # targets, a permuted image) are converted HERE, outside the recording, with a one-time warning: the copies are what the
+        # step reads (a replay copies them into the recorded tensors like any new batch).
+        img = self._as_f32(img, "image batch")
+        tensors = [self._as_f32(g, "target %d" % i) for i, g in enumerate(tensors)]
+        if subnet in ("detection_subnet", "train_both") and self.anno_bucket > 1:
+            ai = 2 if subnet == "train_both" else 0
+            if ai < len(tensors) and tensors[ai].dim() == 3:
+                tensors[ai] = self._bucket_annotations(tensors[ai])
         key = (subnet, tuple(img.shape), img.dtype, tuple((tuple(t.shape), t.dtype) for t in tensors))
         ent = self._entries.get(key)
         if ent is not None and ent.sig != self._state_sig():
             ent = None
-            self._entries.pop(key)
+            self._drop(key)
+        if ent is not None:
+            self._entries.move_to_end(key)
         if ent is None:
             n = self._seen.get(key, 0)
             self._seen[key] = n + 1
@@ -172,6 +187,36 @@ class ReplayedTrainStep(object):
                 raise _lib.MpnError("%s failed during replay" % getattr(fn, "__name__", fn))
         self.replays += 1
         return ent.loss, self._log(ent.logv, ent.names)
+
+    def _as_f32(self, t, what):
+        if t.dtype == torch.float32 and t.is_contiguous():
+            return t
+        if what not in self._warned:
+            self._warned.add(what)
+            import warnings
+            warnings.warn("recorded train step: %s arrives as %s, contiguous=%s — converted to contiguous float32 on every step; "
+                          "do it in the data pipeline to save the copy" % (what, t.dtype, t.is_contiguous()))
+        return t.detach().to(torch.float32).contiguous()
+
+    def _bucket_annotations(self, anno):
+        """[B, n, 5] -> [B, ceil(n / bucket) * bucket, 5], the new rows filled with -1 (= padding: losses.py:47 drops them)."""
+        n = anno.shape[1]
+        m = max(self.anno_bucket, (n + self.anno_bucket - 1) // self.anno_bucket * self.anno_bucket)
+        if m == n:
+            return anno
+        out = torch.full((anno.shape[0], m, anno.shape[2]), -1.0, dtype=anno.dtype, device=anno.device)
+        out[:, :n] = anno
+        return out
+
+    def _drop(self, key):
+        """Forget a recording and give its pool back.  The launches of its last replay may still be running on either stream, and
+        the allocator knows nothing of kernels launched through the C ABI: wait for the device first."""
+        ent = self._entries.pop(key, None)
+        if ent is None:
+            return
+        torch.cuda.synchronize()
+        ent.tape = ent.keep = ent.img = ent.gts = ent.logv = ent.loss = None
+        ent.pool = None
 
     @staticmethod
     def _log(logv, names):
@@ -207,4 +252,7 @@ class ReplayedTrainStep(object):
         ent.keep = ops.take_epoch_workspaces(epoch)
         ent.sig = self._state_sig()
         self._entries[key] = ent
+        while len(self._entries) > self.max_entries:          # least recently used recording out (its pool is released)
+            self._drop(next(iter(self._entries)))
+            self.evictions += 1
         return ent

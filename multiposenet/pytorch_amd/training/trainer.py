@@ -102,8 +102,16 @@ class RunningStat(object):
     def reset(self):
         self._n, self._mean, self._m2, self._parked = 0, 0.0, 0.0, []
 
+    PARK_LIMIT = 64        # asynchronous proxies hold a pinned buffer and an event each: never more than this many at once
+
     def add(self, value):
         self._parked.append(value)
+        if len(self._parked) >= self.PARK_LIMIT:
+            # the oldest proxies belong to steps that finished long ago (their copies have landed): folding them does not wait
+            recent = self._parked[-8:]
+            self._parked = self._parked[:-8]
+            self._fold()
+            self._parked = recent
 
     def _fold(self):
         for v in self._parked:

@@ -247,3 +247,57 @@ def test_bench_spawn_path_runs_two_ranks_to_one_json_line():
     assert "cpu_baseline" not in out and out["value"] > 0 and out["scaling"] == "weak"
     report("bench.py --gpus 2 --shared-device-test: spawn -> rendezvous -> 3 data-parallel steps -> one JSON line (%.1f img/s on one shared device, not a measurement)"
            % out["value"])
+
+
+# ------------------------------------------------------------------------------------------------ recorded step: cache bound, conversions
+def test_recorded_step_cache_is_bounded_and_accepts_what_the_eager_step_accepts():
+    """ADVICE r3.  (1) The cache of recordings is an LRU: with max_entries = 2 and three input signatures in rotation the third
+    recording evicts the least recently used one (its MemPool is released) and every step still equals the eager step.  (2) The
+    reference's bbox_collater pads annotations to the per-batch maximum: [B, 5, 5] and [B, 7, 5] annotation tensors are padded with
+    -1 rows to the same 8-row bucket, share ONE recording, and give the eager step's loss on the unpadded tensor bit for bit.
+    (3) float64 targets / a non-contiguous image are converted with a warning instead of aborting training."""
+    import warnings
+    from test_model_gpu import get_model, t
+    from multiposenet.pytorch_amd import synthetic
+    from multiposenet.pytorch_amd.optim import FusedAdam
+    from multiposenet.pytorch_amd.replay import ReplayedTrainStep
+    from multiposenet.pytorch_amd.training.batch_processor import train_step
+    m = get_model(50, torch.float32)
+    for p in m.prn.parameters():
+        p.requires_grad = False
+    m.train()
+    state0 = {k: v.clone() for k, v in m.state_dict().items()}
+    B = 2
+
+    def batch(S, nbox, seed):
+        img = t(synthetic.gen_images(seed, B, S, S)).cuda()
+        anno = torch.from_numpy(synthetic.gen_boxes_gt(seed, B, S, max_n=8))[:, :nbox].contiguous().cuda()
+        return img, anno
+
+    def eager_losses(seq):
+        m.load_state_dict(state0)
+        opt = FusedAdam(m, lr=1e-4)
+        out = [float(train_step(m, opt, [[img, "detection_subnet"]], ["detection_subnet", anno])[0]) for img, anno in seq]
+        torch.cuda.synchronize()
+        return out, m._arena.flat.clone()
+    seq = [batch(128, 5, 1), batch(128, 7, 2), batch(96, 8, 3), batch(160, 8, 4), batch(128, 5, 5), batch(96, 8, 6), batch(160, 8, 7),
+           batch(128, 7, 8), batch(96, 8, 9)]
+    ref, ref_params = eager_losses(seq)
+    m.load_state_dict(state0)
+    opt = FusedAdam(m, lr=1e-4)
+    step = ReplayedTrainStep(m, opt, max_entries=2)
+    got = [float(step([[img, "detection_subnet"]], ["detection_subnet", anno])[0]) for img, anno in seq]
+    torch.cuda.synchronize()
+    assert all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(got, ref)), "recorded step (LRU of 2, bucketed annotations) differs from the eager step:\n%s\n%s" % (got, ref)
+    assert torch.equal(m._arena.flat, ref_params), "parameters after nine steps differ from the eager path's"
+    assert len(step._entries) <= 2 and step.evictions >= 1, (len(step._entries), step.evictions)
+    keys128 = [k for k in step._seen if k[1] == (B, 3, 128, 128)]
+    assert len(keys128) == 1, "5- and 7-row annotation tensors must share one signature after bucketing: %s" % keys128
+    # (3) conversions
+    img, anno = seq[0]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        l64 = float(step([[img.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2), "detection_subnet"]], ["detection_subnet", anno.double()])[0])
+    assert any("converted to contiguous float32" in str(x.message) for x in w)
+    assert np.isfinite(l64)
+    report("recorded step: LRU of 2 over 3 signatures (%d evictions), bucketed annotations, converted inputs — losses equal the eager step" % step.evictions)
