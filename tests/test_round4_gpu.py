@@ -301,3 +301,170 @@ def test_recorded_step_cache_is_bounded_and_accepts_what_the_eager_step_accepts(
     assert any("converted to contiguous float32" in str(x.message) for x in w)
     assert np.isfinite(l64)
     report("recorded step: LRU of 2 over 3 signatures (%d evictions), bucketed annotations, converted inputs — losses equal the eager step" % step.evictions)
+
+
+# ------------------------------------------------------------------------------------------------ bf16 gates beyond the bottlenecks
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-12))
+
+
+def _act(x_nchw, needs_grad=True):
+    from multiposenet.pytorch_amd import ops
+    return ops.Act(x_nchw.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda(), x_nchw.shape[1], needs_grad=needs_grad)
+
+
+def _nchw(act):
+    return act.t[..., : act.C].float().cpu().permute(0, 3, 1, 2)
+
+
+def _bf16_randn(seed, *shape, scale=1.0, relu=False):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(*shape, generator=g) * scale
+    if relu:
+        x = torch.relu(x)
+    return x.to(torch.bfloat16).float()
+
+
+def test_bf16_pyramids_heads_and_stem_against_the_rounding_oracle():
+    """the teacher-forced rounding-model comparison of test_round3_gpu's bottleneck test for the OTHER bf16-only
+    epilogue branches — (i) the FPN top-down steps (lateral 1x1 + nearest-upsample add in the epilogue + 3x3 smooth; fpn.py:84-124,
+    both pyramids, the stride-2 P6 / P7 convolutions), (ii) the keypoint head: convt/convs, conv2 through the VIRTUAL concatenation,
+    convfin and the four intermediate-supervision 1x1 heads with f32 outputs (posenet.py:288-318), (iii) the RetinaNet towers as
+    pyramid launches over five levels incl. the sigmoid edge (posenet.py:33-117,327-328), (iv) the stem: packed 7x7 / stride 2 +
+    batch-statistics BatchNorm + ReLU + max-pool (fpn.py:99-100).  HIP and oracle get the same bf16 inputs and the same output
+    gradients; gates as for the bottlenecks: outputs 2e-3, input gradients 3e-2 (towers 8e-2), parameter gradients 5e-2 rel-L2."""
+    from test_model_gpu import get_model, load_he, t
+    from test_round3_gpu import _oracle_leaves
+    from multiposenet.pytorch_amd import ops, synthetic
+    from multiposenet.pytorch_amd.engine import Ctx
+    from oracle import posenet_oracle as po
+    Q = torch.bfloat16
+    B, S = 2, 128
+    m = get_model(50, Q)
+    sd_np = load_he(m)
+    for p in m.prn.parameters():
+        p.requires_grad = False
+    m.train()
+    eng = m._engine
+    m._prepare(t(synthetic.gen_images(701, B, S, S)).cuda())             # refresh the bf16 operand copies of the weights
+    saved_flags = (eng.overlap_wgrad, eng.det_pyramid_side)
+    eng.overlap_wgrad, eng.det_pyramid_side = False, 0
+    sd, leaves = _oracle_leaves(sd_np)
+    lines = []
+
+    def compare(tag, outs_h, outs_o, xs_h, xs_o, ctx, prefixes, lim=(2e-3, 3e-2, 5e-2)):
+        r_out = max(_rel(h, o.detach()) for h, o in zip(outs_h, outs_o))
+        r_dx = max((_rel(_nchw(ctx.grad_of(xh)), xo.grad) for xh, xo in zip(xs_h, xs_o)), default=0.0)
+        r_dw, worst = 0.0, ""
+        for name, prm in m.named_parameters():
+            if name.startswith(prefixes) and prm.requires_grad:
+                go = leaves[name].grad
+                assert go is not None and float(go.abs().max()) > 0, "%s: the oracle produced no gradient for %s" % (tag, name)
+                r = _rel(prm.grad.detach().float().cpu(), go)
+                if r > r_dw:
+                    r_dw, worst = r, name
+        lines.append("    %-34s out %.2e  dx %.2e  worst dparam %.2e (%s)" % (tag, r_out, r_dx, r_dw, worst))
+        report(lines[-1])
+        assert r_out <= lim[0] and r_dx <= lim[1] and r_dw <= lim[2], lines[-1]
+
+    def fresh():
+        for v in leaves.values():
+            v.grad = None
+        m._arena.ensure_grads()
+        m._arena.grad_flat.zero_()
+        return Ctx(True)
+
+    def run_tape(ctx):
+        while ctx.tape:
+            ctx.tape.pop()()
+        torch.cuda.synchronize()
+    try:
+        cs = [_bf16_randn(710 + i, B, c, h, h, relu=True) for i, (c, h) in enumerate(((256, 32), (512, 16), (1024, 8), (2048, 4)))]
+        # ---- (i) keypoint pyramid: toplayer, flatlayer1-3 with the upsample-add epilogue, smooth1-3
+        ctx = fresh()
+        xs_o = [c.clone().requires_grad_(True) for c in cs]
+        with po.rounding(Q):
+            c2, c3, c4, c5 = [po._q(x) for x in xs_o]
+            fp5 = po._conv(sd, "fpn.toplayer", c5)
+            fp4 = po.upsample_add(fp5, po._conv(sd, "fpn.flatlayer1", c4))
+            fp3 = po.upsample_add(fp4, po._conv(sd, "fpn.flatlayer2", c3))
+            fp2 = po.upsample_add(fp3, po._conv(sd, "fpn.flatlayer3", c2))
+            outs_o = [po._conv(sd, "fpn.smooth3", fp2, padding=1), po._conv(sd, "fpn.smooth2", fp3, padding=1),
+                      po._conv(sd, "fpn.smooth1", fp4, padding=1), fp5]
+        gs = [_bf16_randn(720 + i, *o.shape, scale=0.05) for i, o in enumerate(outs_o)]
+        torch.autograd.backward(outs_o, gs)
+        xs_h = [_act(c) for c in cs]
+        outs_h = eng.kp_pyramid(ctx, *xs_h)
+        for oh, g in zip(outs_h, gs):
+            ctx.set_grad(oh, _act(g, False))
+        run_tape(ctx)
+        compare("(i) keypoint pyramid", [_nchw(o) for o in outs_h], outs_o, xs_h, xs_o, ctx, ("fpn.toplayer.", "fpn.flatlayer", "fpn.smooth"))
+        # ---- (i') detection pyramid: conv6 / conv7 (3x3 stride 2, ReLU between), latlayer1-3 + upsample-add, toplayer0-2
+        ctx = fresh()
+        xs_o = [c.clone().requires_grad_(True) for c in cs[1:]]
+        with po.rounding(Q):
+            c3, c4, c5 = [po._q(x) for x in xs_o]
+            p6 = po._conv(sd, "fpn.conv6", c5, stride=2, padding=1)
+            p7 = po._conv(sd, "fpn.conv7", F.relu(p6), stride=2, padding=1)
+            p5 = po._conv(sd, "fpn.latlayer1", c5)
+            p4 = po.upsample_add(p5, po._conv(sd, "fpn.latlayer2", c4))
+            p3 = po.upsample_add(p4, po._conv(sd, "fpn.latlayer3", c3))
+            outs_o = [po._conv(sd, "fpn.toplayer2", p3, padding=1), po._conv(sd, "fpn.toplayer1", p4, padding=1),
+                      po._conv(sd, "fpn.toplayer0", p5, padding=1), p6, p7]
+        gs = [_bf16_randn(730 + i, *o.shape, scale=0.05) for i, o in enumerate(outs_o)]
+        torch.autograd.backward(outs_o, gs)
+        xs_h = [_act(c) for c in cs[1:]]
+        outs_h = eng.det_pyramid(ctx, *xs_h)
+        for oh, g in zip(outs_h, gs):
+            ctx.set_grad(oh, _act(g, False))
+        run_tape(ctx)
+        compare("(i') detection pyramid", [_nchw(o) for o in outs_h], outs_o, xs_h, xs_o, ctx,
+                ("fpn.conv6.", "fpn.conv7.", "fpn.latlayer", "fpn.toplayer0.", "fpn.toplayer1.", "fpn.toplayer2."))
+        # ---- (ii) keypoint head: intermediate 1x1 heads (f32 out), convt / convs, conv2 over the virtual concatenation, convfin
+        ctx = fresh()
+        fs = [_bf16_randn(740 + i, B, 256, h, h) for i, h in enumerate((32, 16, 8, 4))]
+        xs_o = [f.clone().requires_grad_(True) for f in fs]
+        with po.rounding(Q):
+            pred_o, saved_o = po.keypoint_head(sd, [po._q(x) for x in xs_o], True)
+        outs_o = saved_o                                                    # [k2, k3, k4, k5 (up-sampled), pred], all f32 API tensors
+        gs = [torch.randn(o.shape, generator=torch.Generator().manual_seed(750 + i)) * 0.05 for i, o in enumerate(outs_o)]
+        torch.autograd.backward(outs_o, gs)
+        xs_h = [_act(f) for f in fs]
+        pred_h, saved_h = eng.keypoint_head(ctx, xs_h, True)
+        ctx.out_grads = {"k0": gs[0].cuda(), "k1": gs[1].cuda(), "k2": gs[2].cuda(), "k3": gs[3].cuda(), "pred": gs[4].cuda()}
+        run_tape(ctx)
+        compare("(ii) keypoint head (virtual concat)", [x.float().cpu() for x in saved_h + [pred_h]], outs_o, xs_h, xs_o, ctx,
+                ("convfin", "convt", "convs", "conv2."))
+        # ---- (iii) RetinaNet towers over the five-level pyramid (pyramid launches) + sigmoid edge
+        ctx = fresh()
+        ps = [_bf16_randn(760 + i, B, 256, h, h) for i, h in enumerate((16, 8, 4, 2, 1))]
+        xs_o = [f.clone().requires_grad_(True) for f in ps]
+        with po.rounding(Q):
+            cls_o, reg_o = po.detection_head(sd, [po._q(x) for x in xs_o])
+        gc = torch.randn(cls_o.shape, generator=torch.Generator().manual_seed(770)) * 0.05
+        gr = torch.randn(reg_o.shape, generator=torch.Generator().manual_seed(771)) * 0.05
+        torch.autograd.backward([cls_o, reg_o], [gc, gr])
+        xs_h = [_act(f) for f in ps]
+        cls_h, reg_h = eng.detection_head(ctx, xs_h)
+        ctx.out_grads = {"cls": gc.cuda(), "reg": gr.cuda()}
+        run_tape(ctx)
+        # four ReLU layers per tower and no BatchNorm in between: an activation that rounds to the other side of zero flips a whole
+        # gradient element, so the input gradient carries sqrt(flipped fraction) of noise per layer (measured 5.3e-2; a missing or
+        # misplaced mask gives 0.5 and more) — its gate is 8e-2
+        compare("(iii) detection towers (5 levels)", [cls_h.float().cpu(), reg_h.float().cpu()], [cls_o, reg_o], xs_h, xs_o, ctx,
+                ("regressionModel.", "classificationModel."), lim=(2e-3, 8e-2, 5e-2))
+        # ---- (iv) stem: 7x7 / 2 on the packed image, batch-statistics BatchNorm, ReLU, 3x3 / 2 max-pool
+        ctx = fresh()
+        img = t(synthetic.gen_images(780, B, S, S))
+        with po.rounding(Q):
+            c1 = po._q(F.relu(po._bn(sd, "fpn.bn1", po._conv(sd, "fpn.conv1", po._q(img), stride=2, padding=3), True)))
+            out_o = F.max_pool2d(c1, kernel_size=3, stride=2, padding=1)
+        g = _bf16_randn(781, *out_o.shape, scale=0.05)
+        out_o.backward(g)
+        out_h = eng.stem(ctx, img.cuda())
+        ctx.set_grad(out_h, _act(g, False))
+        run_tape(ctx)
+        compare("(iv) stem + max-pool", [_nchw(out_h)], [out_o], [], [], ctx, ("fpn.conv1.", "fpn.bn1."))
+    finally:
+        eng.overlap_wgrad, eng.det_pyramid_side = saved_flags
+    report("bf16 pyramids / heads / stem vs the same-rounding oracle (R50, teacher-forced): all within 2e-3 / 3e-2 / 5e-2")
