@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--size", type=int, default=480)
     ap.add_argument("--layers", type=int, default=101)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--subnet", default="train_both", choices=["train_both", "keypoint_subnet", "detection_subnet"],
+                    help="train_both = the headline step (BASELINE config 3 / 4); keypoint_subnet = BASELINE config 2's step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--eager-log", action="store_true", help="plain-float loss logs (one host sync per step, the reference's behaviour)")
@@ -274,7 +276,9 @@ def main():
     from multiposenet.pytorch_amd.graph import GraphedTrainStep
     from multiposenet.pytorch_amd.replay import ReplayedTrainStep
     from multiposenet.pytorch_amd.training.batch_processor import train_step
-    inputs, gts = [[img, "train_both"]], ["train_both", heat, wgt, anno]
+    inputs = [[img, args.subnet]]
+    gts = {"train_both": ["train_both", heat, wgt, anno], "keypoint_subnet": ["keypoint_subnet", heat, wgt],
+           "detection_subnet": ["detection_subnet", anno]}[args.subnet]
     if args.no_graph:
         args.launch = "eager"
     gstep = {"replay": lambda: ReplayedTrainStep(model, opt), "graph": lambda: GraphedTrainStep(model, opt), "eager": lambda: None}[args.launch]()
@@ -360,9 +364,12 @@ def main():
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "R%d full posenet (keypoint+detection) train step: fwd + MSE/focal losses + bwd + Adam, "
+            "config": {"workload": "R%d %s train step: fwd + %s + bwd + Adam, "
                                    "%dx%d, %d images/GPU, %s MFMA / fp32 accumulate / fp32 master weights"
-                                   % (args.layers, args.size, args.size, args.batch, args.dtype),
+                                   % (args.layers, {"train_both": "full posenet (keypoint+detection)", "keypoint_subnet": "keypoint subnet",
+                                                    "detection_subnet": "detection subnet"}[args.subnet],
+                                      {"train_both": "MSE/focal losses", "keypoint_subnet": "MSE heat-map loss", "detection_subnet": "focal loss"}[args.subnet],
+                                      args.size, args.size, args.batch, args.dtype),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "loss_log": "eager floats (host sync per step)" if args.eager_log else "asynchronous (set_lazy_log)",
                        "launch": {"eager": "eager Python tape (autograd node + ~2300 ctypes launches built per step)",
@@ -379,7 +386,7 @@ def main():
                                 if k in ("heatmap_loss", "total_loss", "classification_loss", "regression_loss")}   # not waited for
         out["host_enqueue_ms_per_step"] = round(host_free[len(host_free) // 2] * 1000.0, 3)      # empty queue, median of 5
         out["host_enqueue_ms_per_step_in_region"] = round(t_enq / args.steps * 1000.0, 3)       # queue full: follows the GPU
-        gf = GFLOP_PER_IMG_TRAIN.get(("r%d" % args.layers, args.size))
+        gf = GFLOP_PER_IMG_TRAIN.get(("r%d" % args.layers, args.size)) if args.subnet == ("keypoint_subnet" if args.layers == 50 else "train_both") else None
         if gf is not None:
             out["model_tflops_per_gpu"] = round(ips / world * gf / 1000.0, 2)
         if ke_serial:
