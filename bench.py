@@ -175,7 +175,7 @@ def pmc_traffic(kernel_class):
     reads doubled per MI355X_MICROARCH.md).  PMC collection serialises kernels, so it cannot run inside the timed
     bench; None when no profile is present."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_hbm_traffic.json")))      # the headline configuration's (others carry a config tag)
     if not files:
         return None, None
     try:

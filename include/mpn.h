@@ -93,8 +93,8 @@ typedef struct MpnConvParams {
      * the arrival order) and does the work of mpn_bn_finalize_train (stats: fin_out = [4][Cout] mean, invstd, scale, shift;
      * running statistics updated when fin_rm / fin_rv are given) or of mpn_bn_bwd_finalize (bnb_partial: fin_dgamma += ,
      * fin_dbeta += , fin_out = [3][Cout] k1, k2, k3 with fin_train selecting batch-statistics or frozen coefficients; mean /
-     * invstd are bnb_mean / bnb_invstd).  fin_counters: one zeroed uint32 per output-channel tile (64 entries; 64 + 32 * 128 with
-     * fin_group); the launch leaves them zero again.  Launches sharing a counter array must be ordered (one stream).           */
+     * invstd are bnb_mean / bnb_invstd).  fin_counters: one zeroed uint32 per output-channel tile (64 entries); the launch leaves
+     * them zero again.  Launches sharing a counter array must be ordered (one stream).           */
     /* Virtual channel concatenation of the gathered operand (kseg_n > 0; 3x3 / stride 1 / pad 1 launches with 16-bit operands):
      * the input is cat_s(nearest_upsample(kseg_x[s])) over kseg_n <= 4 segments of kseg_c channels each (Cin = kseg_n * kseg_c) —
      * torch.cat((up8(q5), up4(q4), up2(q3), q2), 1) feeding conv2 (network/posenet.py:311-315) — and is never materialised:
@@ -103,18 +103,6 @@ typedef struct MpnConvParams {
     int32_t kseg_n, kseg_c;
     int32_t kseg_shift[4];
     const void* kseg_x[4];
-    /* Split output (y2 != NULL; plain stores only: no residual / accumulate / statistics): output channels >= y2_c0 go to the
-     * dense tensor y2[pixel * y2_sP + (channel - y2_c0)] instead of y — the input gradient of conv2 written straight into the
-     * gradient of the concatenation's full-resolution member (q2) while the up-sampled members' slices stay in y.          */
-    void* y2;
-    int64_t y2_sP;
-    int32_t y2_c0;
-    /* ReLU-backward mask in the epilogue (input-gradient launches): the tensor this launch writes is the gradient w.r.t. a tensor
-     * t = relu(.) produced by a convolution with act 1 (the RetinaNet towers, posenet.py:48-66,91-109; conv2, :313); the consumer
-     * needs d(pre-activation) = gradient * (t > 0).  relu_y = t (geometry / element type / strides of y; pyramid mode: seg_ry[l]):
-     * the stored result is zeroed where t <= 0, which replaces a separate mpn_relu_backward pass over the tensor.            */
-    const void* relu_y;
-    const void* seg_ry[5];
     uint32_t* fin_counters;
     const float* fin_gamma;
     const float* fin_beta;
@@ -126,13 +114,6 @@ typedef struct MpnConvParams {
     double fin_count;
     float fin_momentum, fin_eps;
     int32_t fin_train;
-    /* Two-level in-launch finalize (fin_group = GS > 0, for launches of more than ~64 pixel tiles): the last workgroup of every
-     * group of GS consecutive pixel tiles sums the group's partial rows into one double-precision row of fin_gpart
-     * ([ceil(tiles / GS)][Cout][2] doubles, caller-owned scratch), the last GROUP to finish sums those and finalizes — no workgroup
-     * reads more than max(GS, tiles / GS) rows behind its acquire.  Needs ceil(tiles / GS) <= 128, at most 32 output-channel tiles
-     * and fin_counters of 64 + 32 * 128 zeroed entries.  Same results whatever the arrival order.                          */
-    int32_t fin_group;
-    double* fin_gpart;
     /* Atomic batch statistics (stats_atomic = 1, round 4): `stats` is NOT the per-tile partial table but ONE pair of 64-bit
      * fixed-point accumulators per channel, uint64 [Cout][2], zeroed by the caller before the launch; every workgroup adds its
      * tile's (sum, sum^2) with integer atomics: sum in units of 2^-MPN_STAT_SUM_FRAC_BITS, sum^2 in units of
@@ -152,29 +133,9 @@ int mpn_conv_stats_tiles(const MpnConvParams* p);
 /* output-channel rows of the tile (256 / 128 / 64 / 32) the launcher will pick: names the kernel instantiation */
 int mpn_conv_tile_rows(const MpnConvParams* p);
 /* 1 when the launcher will take conv_igemm_s3_kernel (3x3, stride 1, pad 1, 16-bit operands, dense input: the pixel tile of a kernel
- * row lands once and serves its three taps), 2 when it will take conv_pw_kernel (below), 0 for conv_igemm_kernel: names the kernel
- * instantiation */
+ * row lands once and serves its three taps), 0 for conv_igemm_kernel: names the kernel instantiation */
 int mpn_conv_shared_tile(const MpnConvParams* p);
 int mpn_conv_forward(const MpnConvParams* p, void* stream);
-
-/* Pointwise kernel with the pixel tile resident in LDS (csrc/conv_pw.hip): the 1x1 / stride-1 "expand" convolutions of a
- * Bottleneck (network/fpn.py:14,18,28-33 — conv3 forward, conv1 input gradient) whose contraction is short (Cin = 64 / 128 / 256)
- * and whose output is wide (Cout >= 256, multiple of 64): one workgroup per 128-pixel tile computes ALL output channels from a
- * pixel tile that lands in LDS once.  16-bit element types, dense tensors, epilogue = scale / bias / ReLU / same-size residual /
- * ReLU after it / accumulate / forward or backward BatchNorm tile statistics (no in-launch finalize).  Results are bit-identical to
- * mpn_conv_forward's generic kernel (same k order, same rounding points); the statistics differ in summation order only.
- * mpn_conv_pw_supported: 1 when the kernel serves p.  mpn_conv_pw_selected: 1 when mpn_conv_forward will route p to it by itself
- * (supported, its epilogue class enabled by MPN_PW_EPI_MASK — default: none, the kernel measured no step-level gain, DESIGN.md —
- * and at least mpn_conv_pw_set_min_tiles() pixel tiles, default 96; a threshold of 0 routes everything supported;
- * mpn_conv_shared_tile() then returns 2).  mpn_conv_pw_set_min_tiles(t): t >= 0 sets the threshold, returns the
- * previous value.  mpn_conv_pw_forward: launches it for any supported p (MPN_E_UNSUPPORTED otherwise). */
-int mpn_conv_pw_supported(const MpnConvParams* p);
-int mpn_conv_pw_selected(const MpnConvParams* p);
-int mpn_conv_pw_set_min_tiles(int tiles);
-int mpn_conv_pw_forward(const MpnConvParams* p, void* stream);
-/* tools/pw_timeline.py only: device buffer [workgroups][waves][8] of uint64 that the following conv_pw_kernel launches fill with
- * s_memtime stamps at their phase boundaries (start, tile landed, then per strip: main loop done, stores issued); NULL = off */
-int mpn_conv_pw_debug_stamps(void* buf);
 
 typedef struct MpnWgradParams {
     const void* x;        /* forward input activations (gathered)                                 */
@@ -268,17 +229,6 @@ int mpn_bn_finalize_eval(int C, const float* gamma, const float* beta, const flo
  * what the backward of relu(bn(.) + shortcut) (network/fpn.py:30-33) needs of z, at 1/16 of its bytes. */
 int mpn_bn_act_forward(const void* y, const void* res, void* z, const float* scale, const float* shift,
                        int64_t P, int C, int Cs, int relu, int dtype, uint8_t* mask, void* stream);
-/* mpn_bn_finalize_train + mpn_bn_act_forward in ONE launch (training forward: z = act(bn(y) [+ res]) with batch statistics from the
- * conv epilogue's tile partials `stats` [tiles][C][2]; count = P).  The first ceil(C / 4) workgroups of the grid finalize four
- * channels each — the arithmetic of mpn_bn_finalize_train, same results — publish mean / invstd / scale / shift and bump *flag; all
- * workgroups wait for *flag to reach that count before they read the coefficients.  *flag MUST be zero at launch and is left at
- * ceil(C / 4): the caller zeroes its flag words once per forward pass (one word per BatchNorm layer).  Returns
- * MPN_E_UNSUPPORTED when the tensor is too small for the grid to contain the finalizing workgroups (use the two launches). */
-int mpn_bn_act_finalize_supported(int64_t P, int C, int Cs, int dtype);      /* 1 when the launch below can be used */
-int mpn_bn_act_finalize_forward(const void* y, const void* res, void* z, int64_t P, int C, int Cs, int relu, int dtype, uint8_t* mask,
-                                const float* stats, int tiles, const float* gamma, const float* beta, float* running_mean,
-                                float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
-                                float* shift, uint32_t* flag, void* stream);
 /* Training forward from ATOMIC statistics (MpnConvParams.stats_atomic): acc = uint64 [C][2] fixed-point totals of (sum, sum^2) over
  * the P pixels, complete when this launch starts.  Every workgroup derives the coefficients of ITS channels in its prologue (one
  * channel per thread, shared through LDS: mean = sum / P, biased variance, invstd = 1 / sqrt(var + eps) in double precision as

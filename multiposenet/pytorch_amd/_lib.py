@@ -40,12 +40,9 @@ class ConvParams(ctypes.Structure):
         ("bnb_y", ctypes.c_void_p), ("bnb_z", ctypes.c_void_p), ("bnb_mask", ctypes.c_void_p), ("bnb_mean", ctypes.c_void_p), ("bnb_invstd", ctypes.c_void_p),
         ("bnb_scale", ctypes.c_void_p), ("bnb_shift", ctypes.c_void_p), ("bnb_partial", ctypes.c_void_p), ("bnb_relu", ctypes.c_int32),
         ("kseg_n", ctypes.c_int32), ("kseg_c", ctypes.c_int32), ("kseg_shift", ctypes.c_int32 * 4), ("kseg_x", ctypes.c_void_p * 4),
-        ("y2", ctypes.c_void_p), ("y2_sP", ctypes.c_int64), ("y2_c0", ctypes.c_int32),
-        ("relu_y", ctypes.c_void_p), ("seg_ry", ctypes.c_void_p * 5),
         ("fin_counters", ctypes.c_void_p), ("fin_gamma", ctypes.c_void_p), ("fin_beta", ctypes.c_void_p), ("fin_rm", ctypes.c_void_p),
         ("fin_rv", ctypes.c_void_p), ("fin_out", ctypes.c_void_p), ("fin_dgamma", ctypes.c_void_p), ("fin_dbeta", ctypes.c_void_p),
         ("fin_count", ctypes.c_double), ("fin_momentum", ctypes.c_float), ("fin_eps", ctypes.c_float), ("fin_train", ctypes.c_int32),
-        ("fin_group", ctypes.c_int32), ("fin_gpart", ctypes.c_void_p),
         ("stats_atomic", ctypes.c_int32),
     ]
 
@@ -80,11 +77,6 @@ SIGNATURES = {
     "mpn_prn_scores_compact": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mpn_prn_match_host": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
     "mpn_conv_stats_tiles": (_i, [_PC]),
-    "mpn_conv_pw_supported": (_i, [_PC]),
-    "mpn_conv_pw_selected": (_i, [_PC]),
-    "mpn_conv_pw_set_min_tiles": (_i, [_i]),
-    "mpn_conv_pw_forward": (_i, [_PC, _vp]),
-    "mpn_conv_pw_debug_stamps": (_i, [_vp]),
     "mpn_conv_tile_rows": (_i, [_PC]),
     "mpn_conv_shared_tile": (_i, [_PC]),
     "mpn_conv_forward": (_i, [_PC, _vp]),
@@ -108,8 +100,6 @@ SIGNATURES = {
     "mpn_bn_finalize_eval": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "mpn_bn_act_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "mpn_bn_act_acc_forward": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
-    "mpn_bn_act_finalize_supported": (_i, [_i64, _i, _i, _i]),
-    "mpn_bn_act_finalize_forward": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mpn_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
     "mpn_bn_bwd_finalize": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "mpn_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _vp, _vp]),
@@ -167,7 +157,7 @@ SIGNATURES = {
 }
 
 # entry points that return a count, not a status
-_COUNT_FUNCS = {"mpn_conv_stats_tiles", "mpn_conv_tile_rows", "mpn_conv_shared_tile", "mpn_conv_pw_supported", "mpn_conv_pw_selected", "mpn_conv_pw_set_min_tiles", "mpn_conv_wgrad_chunks", "mpn_conv_wgrad_seg_plan", "mpn_conv_wgrad_kernel_id", "mpn_bn_act_finalize_supported", "mpn_bn_bwd_chunks", "mpn_channel_sum_chunks",
+_COUNT_FUNCS = {"mpn_conv_stats_tiles", "mpn_conv_tile_rows", "mpn_conv_shared_tile", "mpn_conv_wgrad_chunks", "mpn_conv_wgrad_seg_plan", "mpn_conv_wgrad_kernel_id", "mpn_bn_bwd_chunks", "mpn_channel_sum_chunks",
                 "mpn_mse_chunks", "mpn_mse_train_blocks", "mpn_focal_blocks", "mpn_bce_chunks", "mpn_nms_workspace_bytes", "mpn_nms_batched_workspace_bytes", "mpn_version"}
 
 _lib = None

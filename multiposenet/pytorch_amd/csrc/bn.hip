@@ -70,18 +70,12 @@ __device__ __forceinline__ void reduce_slices(const float* __restrict__ part, in
 }
 
 // One block of the training-mode finalize: 4 channels x 64 tile-slices (the reduction over up to ~14k tiles is the only work: spread
-// it wide).  `publish`: the coefficients are written through to memory (agent-scope stores) for readers in the SAME launch
-// (bn_act_fin_kernel); the stand-alone kernel's readers come after a kernel boundary.
-__device__ __forceinline__ void st_coef(float* p, float v, bool publish) {
-    if (publish) __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-
+// it wide).
 __device__ __forceinline__ void finalize_train_block(int blk, const float* __restrict__ stats, int tiles, int C, double count,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ rm, float* __restrict__ rv, float momentum, float eps,
                                                      float* __restrict__ mean, float* __restrict__ invstd,
-                                                     float* __restrict__ scale, float* __restrict__ shift, double (*sh)[4][4], bool publish) {
+                                                     float* __restrict__ scale, float* __restrict__ shift, double (*sh)[4][4]) {
     const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
     const int c = blk * 4 + cl;
     double s1 = 0.0, s2 = 0.0;
@@ -104,8 +98,8 @@ __device__ __forceinline__ void finalize_train_block(int blk, const float* __res
         if (var < 0.0) var = 0.0;
         const float is = (float)(1.0 / sqrt(var + (double)eps));
         const float sc = g * is;
-        st_coef(mean + c, (float)mu, publish); st_coef(invstd + c, is, publish);
-        st_coef(scale + c, sc, publish); st_coef(shift + c, b - (float)mu * sc, publish);
+        mean[c] = (float)mu; invstd[c] = is;
+        scale[c] = sc; shift[c] = b - (float)mu * sc;
         if (rm) rm[c] = (1.f - momentum) * rm0 + momentum * (float)mu;
         if (rv) {
             const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
@@ -120,7 +114,7 @@ __global__ void bn_finalize_train_kernel(const float* __restrict__ stats, int ti
                                          float* __restrict__ mean, float* __restrict__ invstd,
                                          float* __restrict__ scale, float* __restrict__ shift) {
     __shared__ double sh[2][4][4];
-    finalize_train_block(blockIdx.x, stats, tiles, C, count, gamma, beta, rm, rv, momentum, eps, mean, invstd, scale, shift, sh, false);
+    finalize_train_block(blockIdx.x, stats, tiles, C, count, gamma, beta, rm, rv, momentum, eps, mean, invstd, scale, shift, sh);
 }
 
 __global__ void bn_finalize_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -161,73 +155,6 @@ __global__ void __launch_bounds__(256) bn_act_kernel(const T* __restrict__ y, co
         }
         a.store(z + off);
         if (mask) {                                   // sign bits of the value as stored (rounded to the element type)
-            unsigned bits = 0;
-#pragma unroll
-            for (int k = 0; k < V; ++k) bits |= (Elem<T>::round(a.v[k]) > 0.f ? 1u : 0u) << k;
-            mask[p * q.G + q.g] = (unsigned char)bits;
-        }
-    }
-}
-
-// bn_act with the training-mode finalize inside the launch (the forward chain conv -> finalize -> bn_act -> conv has nothing beside
-// it on the GPU, so the tiny finalize launch costs its kernel boundary in full: 95 of them are 1.6 ms of a 38 ms step).
-// Built, bit-identical, and NOT faster (38.19 vs 38.08 ms/step at best): what the launch boundary saves, the chip-wide wait costs.
-// Off by default (MPN_BN_ACT_FINALIZE=1 turns it on).
-// The first `nfin` = ceil(C / 4) blocks of the grid (linear order: workgroups are dispatched in that order, so they are resident
-// before any block that waits for them) each finalize four channels exactly as bn_finalize_train_kernel does, publish the
-// coefficients write-through and bump *flag; every block — its first tensor loads already in flight — then waits until *flag has
-// reached nfin, and proceeds as bn_act_kernel.  *flag must be zero at launch (the caller zeroes its flag slots once per forward pass).
-template <typename T>
-__global__ void __launch_bounds__(256) bn_act_fin_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ z,
-                                                         long P, int C, int Cs, int relu, int iters, unsigned char* __restrict__ mask,
-                                                         const float* __restrict__ stats, int tiles, double count,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float* __restrict__ rm, float* __restrict__ rv, float momentum, float eps,
-                                                         float* __restrict__ mean, float* __restrict__ invstd,
-                                                         float* __restrict__ scale, float* __restrict__ shift,
-                                                         unsigned* __restrict__ flag, int nfin) {
-    constexpr int V = Vec16<T>::N;
-    __shared__ double sh[2][4][4];
-    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
-    if (bid < nfin) {
-        finalize_train_block(bid, stats, tiles, C, count, gamma, beta, rm, rv, momentum, eps, mean, invstd, scale, shift, sh, true);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the write-through stores have left before the flag moves
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const Geo<T> q(Cs);
-    const long p0 = (long)blockIdx.x * q.lanes * iters + q.pl;
-    // the first pixel's tensor loads do not depend on the coefficients: in flight while the block waits
-    Vec16<T> a, r;
-    const bool first = p0 < P;
-    if (first) { a.load(y + p0 * Cs + q.c0); if (res) r.load(res + p0 * Cs + q.c0); }
-    if (threadIdx.x == 0) {
-        // long back-off: thousands of resident blocks poll one word, and every poll is a round trip to memory that the finalizing
-        // blocks' stores queue behind (s_sleep 2: +0.7 ms/step, 20: +0.8, 127: +0.1)
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nfin) __builtin_amdgcn_s_sleep(127);
-        // No agent-scope acquire (a buffer_inv of the XCD's L2 per BLOCK: +5 ms/step): the coefficient lines cannot be stale in any
-        // cache of this launch — nobody reads them before the flag is complete, and the flag moves only after the write-through
-        // stores have left (caches start a launch invalidated).  The workgroup fence keeps the compiler from hoisting the loads.
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    __syncthreads();
-    float sc[V], sf[V];
-    load_coef<V>(scale, q.c0, C, sc, 0.f);
-    load_coef<V>(shift, q.c0, C, sf, 0.f);
-    for (int it = 0; it < iters; ++it) {
-        const long p = p0 + (long)it * q.lanes;
-        if (p >= P) break;
-        const long off = p * Cs + q.c0;
-        if (it > 0) { a.load(y + off); if (res) r.load(res + off); }
-#pragma unroll
-        for (int k = 0; k < V; ++k) {
-            float x = a.v[k] * sc[k] + sf[k];
-            if (res) x += r.v[k];
-            if (relu) x = fmaxf(x, 0.f);
-            a.v[k] = (q.c0 + k < C) ? x : 0.f;
-        }
-        a.store(z + off);
-        if (mask) {
             unsigned bits = 0;
 #pragma unroll
             for (int k = 0; k < V; ++k) bits |= (Elem<T>::round(a.v[k]) > 0.f ? 1u : 0u) << k;
@@ -511,31 +438,6 @@ extern "C" int mpn_bn_act_acc_forward(const void* y, const void* res, void* z, i
     MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_acc_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)y, (const T*)res,
                            (T*)z, (long)P, C, Cs, relu, iters, (unsigned char*)mask, (const unsigned long long*)acc, 1.0 / (double)P, unbias,
                            gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift));
-    return mpn_launch_status();
-}
-
-extern "C" int mpn_bn_act_finalize_supported(int64_t P, int C, int Cs, int dtype) {
-    const int V = dtype == MPN_F32 ? 4 : 8;
-    if (P <= 0 || C <= 0 || Cs < C || !geo_ok(Cs, V) || C % 4 != 0) return 0;
-    const int lanes = geo_lanes(Cs, V), iters = pick_iters(P, lanes);
-    const long blocks = ((P + (long)lanes * iters - 1) / ((long)lanes * iters)) * geo_yblocks(Cs, V);
-    return blocks >= (C + 3) / 4 ? 1 : 0;
-}
-
-extern "C" int mpn_bn_act_finalize_forward(const void* y, const void* res, void* z, int64_t P, int C, int Cs, int relu, int dtype, uint8_t* mask,
-                                           const float* stats, int tiles, const float* gamma, const float* beta, float* running_mean,
-                                           float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
-                                           float* shift, uint32_t* flag, void* stream) {
-    MPN_CHECK_ARG(y && z && stats && tiles > 0 && mean && invstd && scale && shift && flag && P > 0 && C > 0 && Cs >= C && (!mask || relu));
-    const int V = dtype == MPN_F32 ? 4 : 8;
-    MPN_CHECK_ARG(geo_ok(Cs, V) && C % 4 == 0);
-    const int lanes = geo_lanes(Cs, V), iters = pick_iters(P, lanes);
-    dim3 grid((unsigned)((P + (long)lanes * iters - 1) / ((long)lanes * iters)), (unsigned)geo_yblocks(Cs, V));
-    const int nfin = (C + 3) / 4;
-    if ((long)grid.x * grid.y < nfin) return MPN_E_UNSUPPORTED;     // fewer blocks than finalizers: use the two separate launches
-    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_fin_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)y, (const T*)res,
-                           (T*)z, (long)P, C, Cs, relu, iters, (unsigned char*)mask, stats, tiles, (double)P, gamma, beta, running_mean,
-                           running_var, momentum, eps, mean, invstd, scale, shift, (unsigned*)flag, nfin));
     return mpn_launch_status();
 }
 

@@ -159,13 +159,9 @@ __device__ __forceinline__ void stat_atomic_add(float* stats, int cout, int comp
 // In-launch finalize (mpn.h: fin_*).  Every workgroup of channel tile `tc` has published its partial pair per channel; the one that
 // draws the last ticket reduces the column [ntiles][TC] in a fixed order (SL interleaved slices per channel in double precision,
 // combined in slice order) — the same numbers whichever workgroup arrives last — and writes the BatchNorm coefficients.
-// With fin_group = GS > 0 the reduction has two levels, so that no single workgroup reads hundreds of rows behind an acquire (one
-// dependent round trip to memory per eight rows: 28 us at 225 tiles): the last arriver of every GROUP of GS consecutive pixel tiles
-// sums its group's rows and publishes a double-precision group row (while other groups are still computing), and the last group to
-// finish sums the <= 128 group rows.  Fixed orders on both levels: deterministic.
-constexpr int FIN_TOP_COUNTERS = 64;        // fin_counters[0 .. 64): one per channel tile; then [channel tile][FIN_MAX_GROUPS] group tickets
-constexpr int FIN_MAX_GROUPS = 128;
-constexpr int FIN_MAX_CTILES = 32;
+// (A two-level form — groups of ~sqrt(tiles) pixel tiles reduced by their own last arrivers — and a finalize inside the bn_act launch
+// were built in round 3, measured 0.2 - 0.3 ms/step SLOWER than the separate finalize launch for the larger layers, and removed in
+// round 4: DESIGN.md section 5.)
 
 template <typename E2, int SL>
 __device__ __forceinline__ void fin_sum_rows(const E2* __restrict__ col, long stride, int r0, int r1, int sl, double& s1, double& s2) {
@@ -208,35 +204,9 @@ __device__ __forceinline__ void fin_last_arriver(const MpnConvParams& p, int c0,
     const float* __restrict__ part = p.stats ? p.stats : p.bnb_partial;
     const int cl = t % TC, sl = t / TC;
     const int c = c0 + cl;
-    const int GS = p.fin_group;
     double s1 = 0.0, s2 = 0.0;
-    if (GS > 0) {
-        const int g = tp / GS, ngroups = (ntiles + GS - 1) / GS;
-        const int r0 = g * GS, r1 = (r0 + GS < ntiles) ? r0 + GS : ntiles;
-        if (!fin_ticket(p.fin_counters + FIN_TOP_COUNTERS + tc * FIN_MAX_GROUPS + g, (unsigned)(r1 - r0 - 1), flag)) return;
-        if (c < p.Cout) fin_sum_rows<float2, SL>(reinterpret_cast<const float2*>(part) + c, (long)p.Cout, r0, r1, sl, s1, s2);
-        if (SL > 1) {
-            lds_d[(sl * TC + cl) * 2 + 0] = s1;
-            lds_d[(sl * TC + cl) * 2 + 1] = s2;
-            __syncthreads();
-            if (sl == 0) {
-                s1 = 0.0; s2 = 0.0;
-#pragma unroll
-                for (int k = 0; k < SL; ++k) { s1 += lds_d[(k * TC + cl) * 2 + 0]; s2 += lds_d[(k * TC + cl) * 2 + 1]; }
-            }
-        }
-        if (sl == 0 && c < p.Cout) {                            // the group's row, published like the tile rows
-            unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.fin_gpart + ((long)g * p.Cout + c) * 2);
-            __hip_atomic_store(dst, (unsigned long long)__double_as_longlong(s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dst + 1, (unsigned long long)__double_as_longlong(s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (!fin_ticket(p.fin_counters + tc, (unsigned)(ngroups - 1), flag)) return;
-        s1 = 0.0; s2 = 0.0;
-        if (c < p.Cout) fin_sum_rows<double2, SL>(reinterpret_cast<const double2*>(p.fin_gpart) + c, (long)p.Cout, 0, ngroups, sl, s1, s2);
-    } else {
-        if (!fin_ticket(p.fin_counters + tc, (unsigned)(ntiles - 1), flag)) return;
-        if (c < p.Cout) fin_sum_rows<float2, SL>(reinterpret_cast<const float2*>(part) + c, (long)p.Cout, 0, ntiles, sl, s1, s2);
-    }
+    if (!fin_ticket(p.fin_counters + tc, (unsigned)(ntiles - 1), flag)) return;
+    if (c < p.Cout) fin_sum_rows<float2, SL>(reinterpret_cast<const float2*>(part) + c, (long)p.Cout, 0, ntiles, sl, s1, s2);
     if (SL > 1) {
         lds_d[(sl * TC + cl) * 2 + 0] = s1;
         lds_d[(sl * TC + cl) * 2 + 1] = s2;
@@ -283,7 +253,7 @@ __device__ __forceinline__ void fin_last_arriver(const MpnConvParams& p, int c0,
 // per-wave LDS staging area and leaves as 16-byte stores with 8..16 lanes covering one pixel's contiguous
 // channels (full 128-byte lines per wave-instruction).
 // EXT (general kernels only) compiles in the rarely used epilogue features — both a residual AND accumulate, BatchNorm-backward
-// statistics with the mask read from the z tensor, the ReLU-backward mask (relu_y), the split output (y2).  The standard general
+// statistics with the mask read from the z tensor, the virtual-concatenation gather (kseg).  The standard general
 // instantiation serves everything the training / inference steps launch by default with ONE added tensor (residual, optionally
 // through mask bits, OR the previous output) and mask bits / recomputation for the statistics: with all features compiled into
 // one kernel the 128-row tile needed 80 - 97 spilled registers at its three-waves-per-SIMD budget (+3.3 ms/step, r03 trace).
@@ -467,15 +437,13 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
             bool live[G];
             unsigned yo[G];                                     // element offsets (launcher: output-shaped tensors < 2^31 elements)
             constexpr int GX = EXT ? G : 1;                      // arrays of the extended features (dead when !EXT)
-            unsigned pixs[GX];
             u32x4_t l_add[G], l_y[G];                            // the added tensor (residual, or the previous output) / bnb_y
             unsigned l_m[G], l_rm[G];                            // mask bytes: bnb_mask / res_mask
-            u32x4_t l_acc[GX], l_z[GX], l_ry[GX];
+            u32x4_t l_acc[GX], l_z[GX];
             const bool add_acc = !EXT && p.res_mode == 0 && p.accumulate;      // standard kernel: accumulate rides in l_add
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 live[g] = pix < P && ccol < p.Cout_store && !(dbg & 128);
-                if (EXT) pixs[g] = pix;
                 yo[g] = b * (unsigned)p.y_sB + rem * (unsigned)p.y_sP + (unsigned)ccol;
                 if (GENERAL && live[g]) {
                     if (p.res_mode != 0) {
@@ -492,7 +460,6 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                     }
                     if (add_acc) l_add[g] = *reinterpret_cast<const u32x4_t*>(Y + yo[g]);
                     if (EXT && p.accumulate) l_acc[g] = *reinterpret_cast<const u32x4_t*>(Y + yo[g]);
-                    if (EXT && p.relu_y) l_ry[g] = *reinterpret_cast<const u32x4_t*>((const OT*)p.relu_y + yo[g]);
                     if (bnb) {
                         l_y[g] = *reinterpret_cast<const u32x4_t*>(Ybn + yo[g]);
                         if (EXT && Zbn) l_z[g] = *reinterpret_cast<const u32x4_t*>(Zbn + yo[g]);
@@ -529,24 +496,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                     }
                     a.store(reinterpret_cast<OT*>(&v));
                 }
-                if (EXT && p.relu_y) {
-                    // ReLU backward: zero where the forward output t <= 0.  A positive float (16- or 32-bit) is a positive signed integer.
-                    if (OSZ == 2) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const unsigned t = l_ry[g][e];
-                            const unsigned m = (((short)(t & 0xffffu)) > 0 ? 0xffffu : 0u) | (((short)(t >> 16)) > 0 ? 0xffff0000u : 0u);
-                            v[e] &= m;
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = ((int)l_ry[g][e] > 0) ? v[e] : 0u;
-                    }
-                }
-                if (EXT && pk.y2 && ccol >= pk.y2_c0)           // split output: channels >= y2_c0 live in their own dense tensor
-                    *reinterpret_cast<u32x4_t*>((OT*)pk.y2 + (long)pixs[g] * pk.y2_sP + (ccol - pk.y2_c0)) = v;
-                else
-                    *reinterpret_cast<u32x4_t*>(Y + yo[g]) = v;
+                *reinterpret_cast<u32x4_t*>(Y + yo[g]) = v;
                 if (bnb) {
                     Vec16<OT> dzv, yy, zz;
                     dzv.load(reinterpret_cast<const OT*>(&v));                  // the value as stored
@@ -672,7 +622,7 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_kernel(const
         for (int k = 1; k < MPN_MAX_SEG; ++k) l += (k < pk.nseg && tp >= pk.seg_tile0[k]) ? 1 : 0;
         l = __builtin_amdgcn_readfirstlane(l);                  // block-uniform: keep the level's geometry in scalar registers
         tp -= pk.seg_tile0[l];
-        p.x = pk.seg_x[l]; p.y = pk.seg_y[l]; p.relu_y = pk.seg_ry[l];
+        p.x = pk.seg_x[l]; p.y = pk.seg_y[l];
         p.H = p.Ho = pk.seg_H[l]; p.W = p.Wo = pk.seg_W[l];
         p.x_sH = (int64_t)p.W * pk.x_sW; p.x_sB = (int64_t)p.H * p.x_sH;
         p.y_sB = (int64_t)p.H * p.W * pk.y_sP;
@@ -840,7 +790,7 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
         for (int k = 1; k < MPN_MAX_SEG; ++k) l += (k < pk.nseg && tp >= pk.seg_tile0[k]) ? 1 : 0;
         l = __builtin_amdgcn_readfirstlane(l);
         tp -= pk.seg_tile0[l];
-        p.x = pk.seg_x[l]; p.y = pk.seg_y[l]; p.relu_y = pk.seg_ry[l];
+        p.x = pk.seg_x[l]; p.y = pk.seg_y[l];
         p.H = p.Ho = pk.seg_H[l]; p.W = p.Wo = pk.seg_W[l];
         p.x_sH = (int64_t)p.W * pk.x_sW; p.x_sB = (int64_t)p.H * p.x_sH;
         p.y_sB = (int64_t)p.H * p.W * pk.y_sP;
@@ -1101,7 +1051,7 @@ int launch_conv_k(const MpnConvParams& p, int tc, long grid, int dbg, hipStream_
 
 // the extended epilogue (see conv_epilogue): only when a launch asks for one of its features
 inline bool conv_needs_ext(const MpnConvParams& p) {
-    return p.relu_y || (p.nseg > 0 && p.seg_ry[0]) || p.y2 || (p.bnb_partial && p.bnb_relu && p.bnb_z && !p.bnb_mask) ||
+    return (p.bnb_partial && p.bnb_relu && p.bnb_z && !p.bnb_mask) ||
            (p.res_mode && p.accumulate) || p.kseg_n > 0;
 }
 
@@ -1115,8 +1065,7 @@ int launch_conv(const MpnConvParams& p, hipStream_t st) {
     if (grid <= 0 || grid > 0x7fffffffL || P >= 0x7fffffffL) return MPN_E_BADARG;
     static const int dbg = getenv("MPN_DEBUG_FLAGS") ? atoi(getenv("MPN_DEBUG_FLAGS")) : 0;   // microbenchmark ablations only
     // "plain" = conv (+ BN tile statistics): no per-element epilogue math at all, lighter register footprint
-    const bool general = p.scale || p.bias || p.res_mode || p.accumulate || p.act || (p.Cout % tc) != 0 || p.bnb_partial || p.y2 ||
-                         p.relu_y || (p.nseg > 0 && p.seg_ry[0]);
+    const bool general = p.scale || p.bias || p.res_mode || p.accumulate || p.act || (p.Cout % tc) != 0 || p.bnb_partial;
     if (conv_needs_ext(p)) {
         if constexpr (OUTF32) return MPN_E_UNSUPPORTED;          // none of the extended features writes f32 from 16-bit operands
         else return launch_conv_k<T, false, true, true>(p, tc, grid, dbg, st);
@@ -1146,7 +1095,6 @@ extern "C" int mpn_conv_tile_rows(const MpnConvParams* p) {
 
 extern "C" int mpn_conv_shared_tile(const MpnConvParams* p) {
     if (!p) return MPN_E_BADARG;
-    if (mpn_conv_pw_selected(p)) return 2;
     const long P = (long)p->B * p->Ho * p->Wo;
     return conv_uses_s3(*p, pick_tc(*p, p->nseg > 0 ? (long)p->seg_tile0[p->nseg] : (P + kTP - 1) / kTP)) ? 1 : 0;
 }
@@ -1174,10 +1122,6 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
             if ((int64_t)p.B * (p.H >> p.kseg_shift[k]) * (p.W >> p.kseg_shift[k]) * p.kseg_c * 2 >= 0x7ffffff0LL) return MPN_E_UNSUPPORTED;
         }
     }
-    MPN_CHECK_ARG(!(p.relu_y || (p.nseg > 0 && p.seg_ry[0])) || (!p.out_f32 && !p.stats && !p.bnb_partial && !p.y2 && !p.act));
-    for (int l = 1; l < p.nseg; ++l) MPN_CHECK_ARG((p.seg_ry[l] != nullptr) == (p.seg_ry[0] != nullptr));
-    MPN_CHECK_ARG(!p.y2 || (p.y2_c0 > 0 && p.y2_c0 % 8 == 0 && p.y2_c0 < p.Cout_store && p.y2_sP >= p.Cout_store - p.y2_c0 && !p.res_mode &&
-                            !p.accumulate && !p.stats && !p.bnb_partial && !p.nseg && !p.out_f32));
     MPN_CHECK_ARG(p.w && p.B > 0);
     MPN_CHECK_ARG(mpn_dtype_ok(p.dtype));
     const int kc = p.dtype == MPN_F32 ? 16 : 32;
@@ -1194,11 +1138,6 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     MPN_CHECK_ARG(!p.stats_atomic || (p.stats_atomic == 1 && p.stats && !p.fin_counters && !p.nseg));
     MPN_CHECK_ARG(!p.fin_counters || (((p.stats != nullptr) != (p.bnb_partial != nullptr)) && p.fin_count > 0 && !p.nseg &&
                                       (p.stats ? p.fin_out != nullptr : true)));
-    if (p.fin_counters && p.fin_group) {                       // two-level finalize: group / channel-tile ticket ranges (mpn.h)
-        const long tiles = ((long)p.B * p.Ho * p.Wo + kTP - 1) / kTP;
-        MPN_CHECK_ARG(p.fin_group > 0 && p.fin_gpart && (tiles + p.fin_group - 1) / p.fin_group <= FIN_MAX_GROUPS &&
-                      (p.Cout_store + pick_tc(p, tiles) - 1) / pick_tc(p, tiles) <= FIN_MAX_CTILES);
-    }
     MPN_CHECK_ARG(!p.bnb_partial || (p.bnb_y && p.bnb_mean && p.bnb_invstd && !p.out_f32 && !p.nseg && !p.stats && !p.act &&
                                      (!p.bnb_relu || p.bnb_z || p.bnb_mask || (p.bnb_scale && p.bnb_shift)) &&
                                      (!p.bnb_mask || (p.y_sB == (int64_t)p.Ho * p.Wo * p.y_sP && p.y_sP == p.Cout_store))));
@@ -1213,7 +1152,6 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
         if (ye >= 0x7fffffffLL) return MPN_E_UNSUPPORTED;
     }          // activation is applied before the residual stage
     hipStream_t st = (hipStream_t)stream;
-    if (mpn_conv_pw_selected(&p)) return mpn_conv_pw_forward(&p, stream);   // short-K wide-output 1x1: pixel tile resident in LDS (conv_pw.hip)
     if (p.dtype == MPN_F32) return launch_conv<float, false>(p, st);       // OT == T == float
     if (p.dtype == MPN_F16) return p.out_f32 ? launch_conv<f16_t, true>(p, st) : launch_conv<f16_t, false>(p, st);
     return p.out_f32 ? launch_conv<bf16_t, true>(p, st) : launch_conv<bf16_t, false>(p, st);

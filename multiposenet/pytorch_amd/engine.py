@@ -40,8 +40,6 @@ class Ctx(object):
         self.side_deferred = []  # side-stream closures held back for later fork points (Engine.side_defer)
         self.side_count = 0
         self.fwd_side_join = False   # forward work is in flight on the side stream (Engine.det_pyramid): join before it is consumed
-        self.fin_flags = None    # zeroed flag words of the fused finalize + bn_act launches of this pass (Engine._fin_flag)
-        self.fin_flag_next = 0
         self.stat_acc = None     # int64 [total BatchNorm channels, 2]: this pass's atomic statistics accumulators (Engine._stat_acc)
         self.stat_acc_next = 0
         self.lazy_res = {}       # id(Act) -> (dz, mask bits): shortcut gradient dz * (z > 0) NOT materialised; the convolution whose
@@ -101,9 +99,6 @@ class Engine(object):
         self.fuse_bn_finalize = os.environ.get("MPN_BN_FUSED_FINALIZE", "1") != "0"
         # forward: the detection pyramid runs on the side stream (0 = off, 1 = only its two tiny-grid stride-2 convolutions P6 / P7)
         self.det_pyramid_side = int(os.environ.get("MPN_DET_PYRAMID_SIDE", "2"))
-        # training forward: the finalize of layers too large for the in-launch form rides in the first blocks of the bn_act launch.
-        # Bit-identical and measured no faster (the chip-wide wait costs what the kernel boundary saved): off
-        self.fuse_bn_act_finalize = os.environ.get("MPN_BN_ACT_FINALIZE", "0") == "1"
         # relu(bn3(.) + shortcut): the forward also writes the sign bits of z (1/16 of its bytes); both backward passes that need
         # the ReLU mask (statistics in the dgrad epilogue, bn_bwd_apply) read those instead of z
         self.bn_mask_bits = os.environ.get("MPN_BN_MASK_BITS", "1") != "0"
@@ -113,12 +108,6 @@ class Engine(object):
         # torch.cat((up8(q5), up4(q4), up2(q3), q2), 1) -> conv2 (posenet.py:311-315): the 512-channel tensor is never written; conv2's
         # forward and weight-gradient launches gather from the four members, its input gradient lands in q2's gradient directly
         self.virtual_concat = os.environ.get("MPN_VIRTUAL_CONCAT", "1") != "0"
-        self.cat_split_dgrad = os.environ.get("MPN_CAT_SPLIT_DGRAD", "0") != "0"
-        # relu(conv(.)) layers (RetinaNet towers, conv2): the ReLU-backward mask can be applied by the input-gradient launch that
-        # PRODUCES the gradient (MpnConvParams.relu_y) instead of a separate relu_backward pass over it.  Bit-identical, and measured
-        # neutral (41.55 vs 41.67 ms in one call: the pass it removes costs what the extra epilogue load of eight MFMA-bound tower
-        # launches costs, which also lose the lighter "plain" kernel): off by default
-        self.fuse_relu_bwd = os.environ.get("MPN_FUSE_RELU_BWD", "0") != "0"
         # training forward, OFF by default (measured neutral): the conv epilogue adds its tile statistics to per-channel 64-bit
         # fixed-point accumulators with integer atomics (order-independent, deterministic) and bn_act derives the coefficients in its
         # prologue, so the finalize launch between conv and bn_act — 16 us of dependent kernel boundary per BatchNorm layer, 1.6 ms a
@@ -362,7 +351,7 @@ class Engine(object):
             return
         if dy.t.dtype != self.cdt:
             raise ops._lib.MpnError("gradient dtype mismatch for %s" % y.tag)
-        if act == 1 and not dy.premasked:
+        if act == 1:
             dy = ops.relu_backward(dy, y)
         elif act == 2:
             raise ops._lib.MpnError("sigmoid backward is handled at the detection edge")
@@ -397,8 +386,6 @@ class Engine(object):
             g, existed = ctx.gbuf(x)
             lazy = ctx.lazy_res.pop(id(x), None)      # (dz, bits) of the identity shortcut: added in this launch's epilogue
             wt = self.w_t(ctx, layer)
-            # x = relu(conv(.)) consumed by convolutions only: every contribution to its gradient is masked where it is produced
-            mask_here = self.fuse_relu_bwd and x.relu_out and x.other_cons == 0 and (not existed or g.premasked)
             bnb = None
             if x.cons == 0 and x.bn_src is not None and self.fuse_bn_stats:
                 # this launch completes dz of the BatchNorm that produced x: its backward statistics ride in the epilogue
@@ -417,8 +404,7 @@ class Engine(object):
                                            res=lazy[0], res_mode=1, res_mask=lazy[1])
             else:
                 _, part = ops.conv_forward(dy, wt, I, R, S, stride, pad, mode=1, out_hw=(x.H, x.W), cin=wt.shape[3], out=g, accumulate=existed,
-                                           bnb=bnb, relu_y=x if (mask_here and bnb is None) else None)
-                g.premasked = bool(mask_here and bnb is None)
+                                           bnb=bnb)
             if bnb is not None:
                 ctx.bnb[id(x)] = part
 
@@ -456,7 +442,7 @@ class Engine(object):
             return
         if any(d is None for d in dys):
             raise ops._lib.MpnError("pyramid convolution: gradient missing for some levels")
-        if act == 1 and not all(d.premasked for d in dys):          # ReLU mask over the whole pyramid in one launch when both sides are single buffers
+        if act == 1:          # ReLU mask over the whole pyramid in one launch when both sides are single buffers
             fd, fy = ops.seg_flat(dys), ops.seg_flat(ys)
             if fd is not None and fy is not None and fd.numel() == fy.numel():
                 out = ops.alloc_seg(ys, ys[0].C, dys[0].t.dtype)
@@ -492,29 +478,11 @@ class Engine(object):
             else:
                 pairs = [ctx.gbuf(x) for x in xs]
                 gs, existed = [g for g, _ in pairs], [e for _, e in pairs]
-            # inputs that are relu(conv(.)) of the previous tower layer: mask their gradient in this launch's epilogue
-            mask_here = self.fuse_relu_bwd and all(x.relu_out and x.other_cons == 0 and x.cons == 0 for x in xs) and \
-                all((not e) or g.premasked for g, e in zip(gs, existed))
             if all(existed) or not any(existed):
-                ops.conv_forward_seg(dys, wt, I, R, S, pad, mode=1, cin=wt.shape[3], outs=gs, accumulate=existed[0],
-                                     relu_ys=xs if mask_here else None)
+                ops.conv_forward_seg(dys, wt, I, R, S, pad, mode=1, cin=wt.shape[3], outs=gs, accumulate=existed[0])
             else:
                 for d, x, g, e in zip(dys, xs, gs, existed):
-                    ops.conv_forward(d, wt, I, R, S, 1, pad, mode=1, out_hw=(x.H, x.W), cin=wt.shape[3], out=g, accumulate=e,
-                                     relu_y=x if mask_here else None)
-            for g in gs:
-                g.premasked = bool(mask_here)
-
-    def _fin_flag(self, ctx, device):
-        """One zeroed uint32 word per fused finalize + bn_act launch of this pass (mpn.h: mpn_bn_act_finalize_forward): a block of
-        words zeroed by ONE fill launch when the pass first needs it (recorded steps re-zero it on every replay)."""
-        if ctx.fin_flags is None or ctx.fin_flag_next >= ctx.fin_flags.numel():
-            ctx.fin_flags = torch.empty(512, dtype=torch.float32, device=device)       # 0.0f == the all-zero word
-            call("mpn_fill_f32", ops.ptr(ctx.fin_flags), 0.0, ctx.fin_flags.numel(), ops.stream_ptr())
-            ctx.fin_flag_next = 0
-            ctx.keep.append(ctx.fin_flags)
-        ctx.fin_flag_next += 1
-        return ctx.fin_flags.data_ptr() + 4 * (ctx.fin_flag_next - 1)
+                    ops.conv_forward(d, wt, I, R, S, 1, pad, mode=1, out_hw=(x.H, x.W), cin=wt.shape[3], out=g, accumulate=e)
 
     def bn(self, ctx, y, stats, layer, relu, res=None, tag=""):
         train_stats = layer.training
@@ -528,15 +496,8 @@ class Engine(object):
                 z, st = ops.bn_act_acc(y, stats, layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var,
                                        momentum, layer.eps, relu, res=res, tag=tag, want_mask=want_mask)
             else:
-                fused = None
-                if self.fuse_bn_act_finalize:          # finalize inside the bn_act launch: one kernel boundary less in the forward chain
-                    fused = ops.bn_act_finalize(y, stats, layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var,
-                                                momentum, layer.eps, relu, self._fin_flag(ctx, y.t.device), res=res, tag=tag, want_mask=want_mask)
-                if fused is not None:
-                    z, st = fused
-                else:
-                    st = ops.bn_finalize_train(stats, y.P, layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var,
-                                               momentum, layer.eps)
+                st = ops.bn_finalize_train(stats, y.P, layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var,
+                                           momentum, layer.eps)
             ctx.bn_train_ran = True
         else:
             st = ops.bn_finalize_eval(layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var, layer.eps)
@@ -711,7 +672,7 @@ class Engine(object):
             if bg:
                 self._grad_done(ctx, bias)
             return
-        if act == 1 and not dy.premasked:
+        if act == 1:
             dy = ops.relu_backward(dy, y)
         ar = self.m._arena
         if wg or bg:
@@ -728,24 +689,18 @@ class Engine(object):
                 self._grad_done(ctx, bias)
         if any(s.needs_grad for s in srcs):
             wt = self.w_t(ctx, layer)
-            last = srcs[-1]
-            # split output (q2's gradient written by the dgrad launch itself): measured slower than the plain kernel plus a slice copy
-            # (1 121 vs 876 + ~50 us: the split needs the extended general epilogue) — off unless MPN_CAT_SPLIT_DGRAD=1
-            direct = self.cat_split_dgrad and last.needs_grad and last.H == H and last.W == W and len(srcs) > 1
-            c0 = sum(s.Cs for s in (srcs[:-1] if direct else srcs))
-            d_rest = Act(torch.empty((dy.B, H, W, c0), dtype=dy.t.dtype, device=dy.t.device), c0)
-            g_last = Act(torch.empty_like(last.t), last.C) if direct else None
-            ops.conv_forward(dy, wt, I, R, S, 1, pad, mode=1, out_hw=(H, W), cin=wt.shape[3], out=d_rest,
-                             split=(g_last, c0) if direct else None)
+            # one buffer of all members' channels, then each member's slice summed down to its own resolution (writing the full-resolution
+            # member's slice straight from the dgrad launch — a split output — measured slower: 1 121 vs 876 + 50 us, round 3; removed)
+            c0 = sum(s.Cs for s in srcs)
+            d_all = Act(torch.empty((dy.B, H, W, c0), dtype=dy.t.dtype, device=dy.t.device), c0)
+            ops.conv_forward(dy, wt, I, R, S, 1, pad, mode=1, out_hw=(H, W), cin=wt.shape[3], out=d_all)
             off = 0
-            for s_ in (srcs[:-1] if direct else srcs):
+            for s_ in srcs:
                 if s_.needs_grad:
                     g = Act(torch.empty_like(s_.t), s_.C)
-                    ops.upsample_slice_backward(d_rest, g, off)
+                    ops.upsample_slice_backward(d_all, g, off)
                     ctx.set_grad(s_, g)
                 off += s_.Cs
-            if direct:
-                ctx.set_grad(last, g_last)
 
     def export(self, ctx, src, C, Ho, Wo, slot):
         """Internal padded tensor -> exact f32 API tensor (nearest up-sampled to Ho x Wo)."""

@@ -85,7 +85,7 @@ class Act(object):
 
     Cs (channel storage) is a multiple of 32; lanes [C, Cs) hold zeros (see include/mpn.h).
     """
-    __slots__ = ("t", "B", "H", "W", "C", "Cs", "needs_grad", "tag", "seg", "cons", "bn_src", "mask", "conv_cons", "relu_out", "premasked", "other_cons")
+    __slots__ = ("t", "B", "H", "W", "C", "Cs", "needs_grad", "tag", "seg", "cons", "bn_src", "mask", "conv_cons", "relu_out", "other_cons")
 
     def __init__(self, t, C, needs_grad=False, tag=""):
         self.t = t
@@ -97,7 +97,6 @@ class Act(object):
         self.cons = 0            # gradient contributions still to come in backward (engine: last-contributor detection)
         self.bn_src = None       # (y, BNState, relu, has_residual) when this is the output of a BatchNorm
         self.relu_out = False    # forward: this tensor is relu(conv(.)) (conv epilogue act 1)
-        self.premasked = False   # gradient tensors: already multiplied by the ReLU mask of the tensor they belong to (dgrad epilogue)
         self.other_cons = 0      # consumers other than plain / pyramid convolutions (residual adds, relu, pooling)
         self.conv_cons = 0       # how many of the pending contributions are input gradients of plain convolutions (engine.conv)
         self.mask = None         # sign bits of this tensor (uint8 [P, Cs / V]) when bn_act produced them for the backward pass
@@ -212,7 +211,7 @@ def seg_flat(acts):
     return flat if sum(a.t.numel() for a in acts) == flat.numel() else None
 
 
-def conv_forward_seg(xs, w, Cout, R, S, pad, bias=None, act=0, out_f32=False, mode=0, outs=None, accumulate=False, cin=None, relu_ys=None):
+def conv_forward_seg(xs, w, Cout, R, S, pad, bias=None, act=0, out_f32=False, mode=0, outs=None, accumulate=False, cin=None):
     """The same convolution (stride 1, same-size output) over every level of a pyramid in ONE launch — the shared RetinaNet
     towers of posenet.py:327-328.  xs: Acts with equal B / C / dtype.  Returns the per-level outputs (views of one buffer)."""
     x0 = xs[0]
@@ -236,9 +235,6 @@ def conv_forward_seg(xs, w, Cout, R, S, pad, bias=None, act=0, out_f32=False, mo
     for l, (x, o) in enumerate(zip(xs, outs)):
         assert (x.B, x.Cs, x.t.dtype) == (x0.B, x0.Cs, dt) and (o.H, o.W, o.Cs, o.t.dtype) == (x.H, x.W, outs[0].Cs, odt)
         p.seg_x[l], p.seg_y[l] = x.t.data_ptr(), o.t.data_ptr()
-        if relu_ys is not None:            # ReLU-backward mask of the tensor whose gradient this launch writes (MpnConvParams.seg_ry)
-            assert relu_ys[l].t.shape == o.t.shape and relu_ys[l].t.dtype == o.t.dtype
-            p.seg_ry[l] = relu_ys[l].t.data_ptr()
         p.seg_H[l], p.seg_W[l] = x.H, x.W
         p.seg_tile0[l] = tile0
         tile0 += (x.B * x.H * x.W + 127) // 128
@@ -247,7 +243,7 @@ def conv_forward_seg(xs, w, Cout, R, S, pad, bias=None, act=0, out_f32=False, mo
         e0 = KERNEL_EVENTS.begin()
         call("mpn_conv_forward", ctypes.byref(p), stream_ptr())
         tc = call("mpn_conv_tile_rows", ctypes.byref(p))
-        general = (bias is not None or accumulate or act != 0 or Cout % tc != 0 or relu_ys is not None)
+        general = (bias is not None or accumulate or act != 0 or Cout % tc != 0)
         name = ("conv_igemm_s3_kernel" if call("mpn_conv_shared_tile", ctypes.byref(p)) == 1 else "conv_igemm_kernel") + "<%s, %d, 128, %s, %s>" % (dtype_name(dt), tc, "true" if p.out_f32 else "false", "true" if general else "false")
         if KERNEL_EVENTS.detail:
             name = "%s %dx%d %d->%d pyramid(%s)|0" % ("dgrad" if mode == 1 else "fwd", R, S, p.Cin, Cout, ",".join(str(x.H) for x in xs))
@@ -402,7 +398,7 @@ def conv_out_hw(H, W, R, S, stride, pad):
 def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, res=None, res_mode=0,
                  want_stats=False, out_f32=False, out=None, accumulate=False, mode=0, out_hw=None,
                  cin=None, x_geom=None, y_geom=None, cout_store=None, needs_grad=False, tag="", bnb=None, bn_fin=None, res_mask=None,
-                 split=None, relu_y=None, stat_acc=None):
+                 stat_acc=None):
     """Implicit-GEMM convolution.  x: Act.  w: compute-dtype tensor laid out [Cout][R][S][Cin].
 
     mode 0 = forward gather, mode 1 = dgrad gather (then ``out_hw`` is the input-gradient size and
@@ -435,16 +431,6 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         p.y = yt.data_ptr()
         p.y_sB, p.y_sP = ysB, ysP
         p.Cout_store = cout_store if cout_store is not None else round_up(Cout, 4)
-    if relu_y is not None:                # ReLU-backward mask in the epilogue (MpnConvParams.relu_y)
-        assert relu_y.t.shape == out.t.shape and relu_y.t.dtype == out.t.dtype
-        p.relu_y = relu_y.t.data_ptr()
-    if split is not None:
-        # split=(y2 Act, c0): output channels >= c0 are written to y2 (dense, y2.Cs channels), the rest to `out` (row stride out.Cs):
-        # the launch computes c0 + y2.C channels in all
-        y2, c0 = split
-        assert y_geom is None and out.Cs >= c0 and (y2.B, y2.H, y2.W) == (x.B, Ho, Wo) and Cout == c0 + y2.C and y2.t.dtype == odt
-        p.y2, p.y2_sP, p.y2_c0 = y2.t.data_ptr(), y2.Cs, c0
-        p.Cout_store = c0 + y2.Cs
     p.x = x.t.data_ptr()
     p.w = w.data_ptr()
     p.bias = bias.data_ptr() if bias is not None else None
@@ -478,7 +464,7 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         else:
             stats = torch.empty((tiles, Cout, 2), dtype=torch.float32, device=dev)
             p.stats = stats.data_ptr()
-        if acc is None and bn_fin is not None and fin_plan(tiles) is not None and not call("mpn_conv_pw_selected", ctypes.byref(p)):
+        if acc is None and bn_fin is not None and fin_in_launch(tiles):
             # the last workgroup of every channel tile turns the tile partials into the BatchNorm coefficients (no finalize launch):
             # the BNState comes back in the stats slot
             gamma, beta, rm, rv, momentum, eps = bn_fin
@@ -503,7 +489,7 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         p.bnb_mean, p.bnb_invstd = st.mean.data_ptr(), st.invstd.data_ptr()
         p.bnb_scale, p.bnb_shift = st.scale.data_ptr(), st.shift.data_ptr()
         p.bnb_relu = 1 if relu else 0
-        if len(bnb) > 4 and bnb[4] is not None and fin_plan(tiles) is not None and not call("mpn_conv_pw_selected", ctypes.byref(p)):
+        if len(bnb) > 4 and bnb[4] is not None and fin_in_launch(tiles):
             # ... and the last workgroup of every channel tile finishes the reduction: dgamma / dbeta and the (k1, k2, k3) of
             # dy = k1*g + k2*y + k3 (mpn_bn_bwd_finalize's work); the coefficient tensor comes back in the stats slot
             gamma, train, dgamma, dbeta = bnb[4]
@@ -524,14 +510,10 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         live = (R * S) / float(stride * stride) if mode == 1 else R * S
         flops = 2.0 * x.B * Ho * Wo * Cout * live * min(Cin, x.C if x_geom is None else Cin)
         # the name rocprofv3 prints for this instantiation (tools/rocprof_summary.py spelling)
-        general = (scale is not None or bias is not None or res is not None or accumulate or act != 0 or Cout % tc != 0 or bnb is not None
-                   or relu_y is not None or split is not None)
+        general = (scale is not None or bias is not None or res is not None or accumulate or act != 0 or Cout % tc != 0 or bnb is not None)
         kind = call("mpn_conv_shared_tile", ctypes.byref(p))
         name = ("conv_igemm_s3_kernel" if kind == 1 else "conv_igemm_kernel") + "<%s, %d, 128, %s, %s>" % (dtype_name(dt), tc,
                                                           "true" if p.out_f32 else "false", "true" if general else "false")
-        if kind == 2:          # pixel tile resident in LDS (csrc/conv_pw.hip)
-            name = "conv_pw_kernel<%s, %d, %d>" % (dtype_name(dt), 8 if Cout >= 512 else 4,
-                                                    2 if (accumulate or bnb is not None) else (1 if (scale is not None or bias is not None or act != 0 or res is not None) else 0))
         if KERNEL_EVENTS.detail:
             es = 2 if is16(dt) else 4
             byts = x.B * H * W * Cin * es + x.B * Ho * Wo * p.Cout_store * (4 if out_f32 else es) * (2 if accumulate else 1) \
@@ -628,34 +610,18 @@ cast_bf16 = cast_lowp
 
 _fin_counters = {}
 # In-launch BatchNorm finalize (mpn.h: fin_*).  Up to FIN_MAX_TILES pixel tiles one workgroup per channel tile does the whole
-# reduction; beyond that a single reader behind an acquire is slower than the separate (wide) finalize launch.  The two-level form
-# (groups of ~sqrt(tiles) pixel tiles, mpn.h: fin_group) up to FIN_GROUP_MAX_TILES tiles is built and tested but OFF: dropping the
-# 95 forward finalize launches of a step from the recorded list measures 1.6 ms (tools/ablate_launches.py), yet every workgroup of
-# a finalizing launch has to drain its stores before it draws a ticket, and that costs more than the launches did
-# (37.85 -> 38.11 ms/step, profiles/r03_bn_finalize_two_level_ab.txt).
+# reduction; beyond that a single reader behind an acquire is slower than the separate (wide) finalize launch (round 2: +0.85 ms at
+# <= 256 tiles), and so were the two-level form and the finalize inside the bn_act launch (round 3: +0.26 / +0.2 ms; both removed).
 FIN_MAX_TILES = int(os.environ.get("MPN_BN_FIN_MAX_TILES", "64"))
-FIN_GROUP_MAX_TILES = int(os.environ.get("MPN_BN_FIN_GROUP_MAX_TILES", "0"))
-FIN_MAX_GROUPS, FIN_COUNTERS = 128, 64 + 32 * 128
+FIN_COUNTERS = 64
 
 
-def fin_plan(tiles):
-    """None: separate finalize launch; 0: one-level in-launch finalize; GS > 0: two levels with groups of GS pixel tiles."""
-    if tiles <= FIN_MAX_TILES:
-        return 0
-    if tiles > FIN_GROUP_MAX_TILES:
-        return None
-    gs = 16
-    while gs * gs < tiles:
-        gs *= 2
-    return gs if (tiles + gs - 1) // gs <= FIN_MAX_GROUPS else None
+def fin_in_launch(tiles):
+    return tiles <= FIN_MAX_TILES
 
 
 def fin_attach(p, tiles, Cout, device):
     p.fin_counters = fin_counters(device).data_ptr()
-    gs = fin_plan(tiles)
-    if gs:
-        p.fin_group = gs
-        p.fin_gpart = workspace(((tiles + gs - 1) // gs) * Cout * 16, device, slot=8).data_ptr()
 
 
 def fin_counters(device):
@@ -723,22 +689,6 @@ def bn_act_acc(y, sacc, gamma, beta, rm, rv, momentum, eps, relu, res=None, need
     call("mpn_bn_act_acc_forward", ptr(y.t), ptr(res.t) if res is not None else None, ptr(z.t), y.P, y.C, y.Cs, 1 if relu else 0,
          dtype_code(y.t.dtype), ptr(z.mask), ptr(sacc.acc), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), momentum, eps,
          ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), stream_ptr())
-    return z, st
-
-
-def bn_act_finalize(y, stats, gamma, beta, rm, rv, momentum, eps, relu, flag, res=None, needs_grad=False, tag="", want_mask=False):
-    """bn_finalize_train + bn_act in one launch (mpn.h: mpn_bn_act_finalize_forward).  flag: a zeroed uint32 word (data pointer) that
-    no other launch uses until it is zeroed again.  Returns (z, BNState), or None when the tensor is too small for the fused launch."""
-    dc = dtype_code(y.t.dtype)
-    if not call("mpn_bn_act_finalize_supported", y.P, y.C, y.Cs, dc):
-        return None
-    st = BNState(y.C, y.t.device)
-    z = Act(torch.empty_like(y.t), y.C, needs_grad, tag)
-    if want_mask and relu:
-        z.mask = torch.empty((y.P, y.Cs // (4 if y.t.dtype == torch.float32 else 8)), dtype=torch.uint8, device=y.t.device)
-    call("mpn_bn_act_finalize_forward", ptr(y.t), ptr(res.t) if res is not None else None, ptr(z.t), y.P, y.C, y.Cs, 1 if relu else 0, dc,
-         ptr(z.mask), ptr(stats), stats.shape[0], ptr(gamma), ptr(beta), ptr(rm), ptr(rv), momentum, eps,
-         ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ctypes.c_void_p(flag), stream_ptr())
     return z, st
 
 

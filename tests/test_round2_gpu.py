@@ -462,19 +462,17 @@ def test_bn_backward_statistics_in_the_dgrad_epilogue(dtype, mode):
 
 
 @pytest.mark.parametrize("dtype,mode,size", [(torch.bfloat16, "train", 160), (torch.float32, "train", 160), (torch.bfloat16, "frozen_affine", 160),
-                                             (torch.bfloat16, "train", 480), (torch.float32, "train", 320)])
+                                             (torch.bfloat16, "train", 320)])
 def test_bn_finalize_inside_the_conv_launch(dtype, mode, size):
     """The last workgroup to finish a channel tile reduces that tile's partial statistics and writes the BatchNorm coefficients
     (MpnConvParams.fin_*): mpn_bn_finalize_train / mpn_bn_bwd_finalize launches disappear from the step.  Same step with the
     in-launch finalize on and off: same loss, running statistics and gradients up to the rounding of one double reduction, and
-    the ticket counters are back at zero.  160x160: every layer has <= 64 pixel tiles (one-level reduction); 320 / 480: layers of
-    100 .. 900 tiles take the two-level reduction (fin_group 16 / 32: group rows by the groups' last arrivers, then the last group)."""
+    the ticket counters are back at zero.  160x160: every layer has <= 64 pixel tiles and finalizes in the launch; 320x320: the larger
+    layers keep their finalize launches (the two-level in-launch form of round 3 was measured slower and removed)."""
     from multiposenet.pytorch_amd.network.posenet import poseNet
     from multiposenet.pytorch_amd import _lib
     import multiposenet.pytorch_amd.ops as ops_mod
     m, inputs, gts = _train_setup(101, dtype, 2, size, seed=151)
-    monkey_group = ops_mod.FIN_GROUP_MAX_TILES
-    ops_mod.FIN_GROUP_MAX_TILES = 16384 if size > 160 else monkey_group      # the two-level form is off by default (measured slower)
     if mode == "frozen_affine":
         m.freeze_bn()
     orig = _lib.call
@@ -502,7 +500,6 @@ def test_bn_finalize_inside_the_conv_launch(dtype, mode, size):
                         {k: v.clone() for k, v in m.state_dict().items() if "running_" in k}))
     finally:
         ops_mod.call = orig
-        ops_mod.FIN_GROUP_MAX_TILES = monkey_group
         m._engine.fuse_bn_finalize = True
         m.train()
     (l0, g0, r0), (l1, g1, r1) = res
@@ -512,7 +509,7 @@ def test_bn_finalize_inside_the_conv_launch(dtype, mode, size):
     rs = max(float((r0[k].float() - r1[k].float()).abs().max() / r0[k].float().abs().max().clamp_min(1e-12)) for k in r0)
     report("BN finalize inside the conv launch (%s, %s, %dx%d): %d -> %d finalize launches; loss rel %.1e, gradient arena rel-L2 %.2e, "
            "running statistics max rel %.1e" % (str(dtype), mode, size, size, calls[0], calls[1], rel_l, rel, rs))
-    assert calls[0] >= len(m._bns) and calls[1] <= 8
+    assert calls[0] >= len(m._bns) and (calls[1] <= 8 if size <= 160 else calls[1] < calls[0])
     assert rel_l <= (1e-6 if dtype == torch.float32 else 1e-3) and rs <= 1e-5
     assert rel <= (2e-5 if dtype == torch.float32 else 1e-2)
 

@@ -241,23 +241,12 @@ def test_trainer_under_two_ranks_writes_once_and_decides_together(tmp_path):
 
 
 def test_host_plans_of_the_round3_launch_options():
-    """Host-side decisions that pick kernels: the in-launch BatchNorm finalize plan (one level up to 64 pixel tiles, two levels with
-    groups of ~sqrt(tiles) only when enabled, never more than 128 groups) and the geometry test of the one-pass heat-map loss."""
+    """Host-side decisions that pick kernels: the in-launch BatchNorm finalize (up to 64 pixel tiles) and the geometry test of the
+    one-pass heat-map loss."""
     import torch
     from multiposenet.pytorch_amd import ops
     from multiposenet.pytorch_amd.network import losses
-    saved = ops.FIN_GROUP_MAX_TILES
-    try:
-        ops.FIN_GROUP_MAX_TILES = 0
-        assert ops.fin_plan(1) == 0 and ops.fin_plan(64) == 0 and ops.fin_plan(65) is None and ops.fin_plan(225) is None
-        ops.FIN_GROUP_MAX_TILES = 16384
-        assert [ops.fin_plan(t) for t in (65, 225, 256, 257, 900, 3600, 14400)] == [16, 16, 16, 32, 32, 64, 128]
-        assert ops.fin_plan(16385) is None
-        for t in (65, 225, 900, 3600, 14400):
-            gs = ops.fin_plan(t)
-            assert (t + gs - 1) // gs <= ops.FIN_MAX_GROUPS
-    finally:
-        ops.FIN_GROUP_MAX_TILES = saved
+    assert ops.fin_in_launch(1) and ops.fin_in_launch(ops.FIN_MAX_TILES) and not ops.fin_in_launch(ops.FIN_MAX_TILES + 1) and not ops.fin_in_launch(225)
     B, H, W = 2, 24, 40
     lv = [ops.Act(torch.zeros(B, H >> s, W >> s, 32), c) for s, c in ((0, 19), (1, 19), (2, 19), (3, 19), (0, 18))]
     heat = torch.zeros(B, 18, H, W)

@@ -162,85 +162,6 @@ def test_trainer_uses_the_recorded_step_and_tester_val_matches_a_hand_loop(tmp_p
     report("Trainer(poseNet, FusedAdam): 5 steps through the recorded list == eager loop bit for bit; Tester.val mean %.6f == hand loop" % mean)
 
 
-# ------------------------------------------------------------------------------------------------ pixel-tile-resident 1x1 kernel
-def _pw_threshold(v):
-    from multiposenet.pytorch_amd._lib import call
-    return call("mpn_conv_pw_set_min_tiles", int(v))
-
-
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-def test_pw_kernel_is_bit_identical_to_the_generic_kernel(dt):
-    """csrc/conv_pw.hip against conv_igemm.hip on the same operands (through mpn_conv_forward with the routing threshold at 0 and
-    at infinity): outputs bit-identical for every epilogue (plain, forward BN statistics, folded-BN scale/shift + ReLU + residual
-    + ReLU, bias + ReLU, accumulate, accumulate + BN-backward statistics with and without the ReLU mask), tile statistics equal
-    up to summation order; plus the plain result against a float64 CPU convolution.  Sizes include a ragged last pixel tile."""
-    from helpers import check_close, from_act, rnd, rng_normal, to_act, w_krsc
-    from multiposenet.pytorch_amd import ops
-    from multiposenet.pytorch_amd._lib import ConvParams, call
-    old = _pw_threshold(-1)
-    try:
-        for (B, H, W, Cin, Cout) in ((2, 17, 19, 256, 1024), (1, 16, 16, 64, 256), (3, 9, 11, 128, 512), (1, 13, 10, 256, 256), (2, 8, 8, 64, 512)):
-            x = rnd(dt, rng_normal(1, B, Cin, H, W))
-            w = rnd(dt, rng_normal(2, Cout, Cin, 1, 1) * 0.05)
-            xa, wk = to_act(x, dt), w_krsc(w, dt)
-            res = to_act(rnd(dt, rng_normal(3, B, Cout, H, W)), dt)
-            scale = (torch.rand(Cout, generator=torch.Generator().manual_seed(4)) + 0.5).cuda()
-            bias = rng_normal(5, Cout).cuda()
-            prev = rnd(dt, rng_normal(6, B, Cout, H, W))
-            by, bz = to_act(rnd(dt, rng_normal(7, B, Cout, H, W)), dt), to_act(rnd(dt, rng_normal(8, B, Cout, H, W)), dt)
-            st = ops.BNState(Cout, torch.device("cuda"))
-            st.mean.copy_(rng_normal(9, Cout) * 0.1); st.invstd.copy_(torch.rand(Cout) + 0.5); st.scale.fill_(1.0); st.shift.fill_(0.0)
-            cases = {
-                "plain": dict(),
-                "stats": dict(want_stats=True),
-                "fold+relu+res+relu": dict(scale=scale, bias=bias, act=3, res=res, res_mode=1),
-                "bias+relu": dict(bias=bias, act=1),
-                "res": dict(res=res, res_mode=1),
-                "acc": dict(accumulate=True),
-                "acc+bnb(relu,z)": dict(accumulate=True, bnb=(by, bz, st, True)),
-                "bnb(no relu)": dict(bnb=(by, None, st, False)),
-            }
-            for name, kw in cases.items():
-                outs = []
-                for thr in (1 << 30, 0):
-                    _pw_threshold(thr)
-                    kw2 = dict(kw)
-                    if kw.get("accumulate") or "bnb" in kw:
-                        kw2["out"] = to_act(prev, dt)
-                    y, s = ops.conv_forward(xa, wk, Cout, 1, 1, 1, 0, **kw2)
-                    torch.cuda.synchronize()
-                    outs.append((y.t.clone(), None if s is None else s.clone()))
-                p = ConvParams()
-                (yg, sg), (yp, sp) = outs
-                tag = "%s pw %s B%d %dx%d %d->%d" % (str(dt).split(".")[-1], name, B, H, W, Cin, Cout)
-                assert torch.equal(yg.view(torch.int16), yp.view(torch.int16)), tag + ": output differs from the generic kernel"
-                if sg is not None:
-                    err = float((sg.double() - sp.double()).abs().max()) / max(float(sg.double().abs().max()), 1e-9)
-                    assert sg.shape == sp.shape and err <= 2e-5, tag + ": tile statistics differ (%.2e)" % err
-                if name == "plain":
-                    ref = torch.nn.functional.conv2d(x.double(), w.double()).float()
-                    check_close(tag + " vs f64", from_act(ops.Act(yp, Cout)), rnd(dt, ref), dt)
-        # the routing itself: selected for the bench shape, not for what the kernel does not serve
-        _pw_threshold(old)
-        p = ConvParams()
-        p.B, p.H, p.W, p.Ho, p.Wo, p.Cin, p.Cout, p.Cout_store = 32, 30, 30, 30, 30, 256, 1024, 1024
-        p.R = p.S = p.stride = 1
-        p.dtype = ops.dtype_code(dt)
-        p.x_sW, p.x_sH, p.x_sB, p.y_sP, p.y_sB = 256, 30 * 256, 900 * 256, 1024, 900 * 1024
-        import ctypes
-        ref_p = ctypes.byref(p)
-        assert call("mpn_conv_pw_supported", ref_p) == 1
-        assert call("mpn_conv_pw_selected", ref_p) == (1 if os.environ.get("MPN_PW_EPI_MASK", "0") not in ("", "0") else 0)     # routed only on request
-        _pw_threshold(0)
-        assert call("mpn_conv_pw_selected", ref_p) == 1 and call("mpn_conv_shared_tile", ref_p) == 2
-        p.Cin = 512
-        assert call("mpn_conv_pw_supported", ref_p) == 0
-        _pw_threshold(old)
-    finally:
-        _pw_threshold(old)
-    report("conv_pw_kernel (%s): 8 epilogues x 5 shapes bit-identical to conv_igemm_kernel, statistics within 2e-5" % str(dt).split(".")[-1])
-
-
 # ------------------------------------------------------------------------------------------------ bf16 drift with teeth
 def _oracle_leaves(sd_np):
     sd = {k: torch.from_numpy(v).clone() for k, v in sd_np.items() if v.dtype != np.int64}
@@ -445,8 +366,8 @@ def test_relu_mask_bits_replace_z_in_both_backward_passes(dtype):
 def test_virtual_concat_equals_the_materialised_concatenation(dtype):
     """posenet.py:311-315: conv2 over torch.cat((up8(q5), up4(q4), up2(q3), q2), 1).  The 512-channel tensor is never written:
     conv2's forward (shared-tile 3x3 kernel) and weight-gradient (LDS-DMA kernel) launches gather from the four members with the
-    nearest-neighbour index in the DMA address, the input-gradient launch writes q2's share straight into q2's gradient.  Same
-    k-order, same slices: outputs, weight / bias gradients and member gradients are bit-identical to the materialised path —
+    nearest-neighbour index in the DMA address.  Same k-order, same slices: outputs and weight / bias gradients are bit-identical to
+    the materialised path —
     at kernel level on odd sizes, and for a whole training step (loss, every gradient)."""
     from multiposenet.pytorch_amd import ops
     from multiposenet.pytorch_amd.network.posenet import poseNet
@@ -468,16 +389,6 @@ def test_virtual_concat_equals_the_materialised_concatenation(dtype):
         dw_vir = torch.zeros_like(dw_ref); db_vir = torch.zeros_like(db_ref)
         assert ops.conv_wgrad(cat, dy, dw_ref, 256, 3, 3, 1, 1, db=db_ref) and ops.conv_wgrad_cat(srcs, H, W, dy, dw_vir, 256, db=db_vir)
         assert torch.equal(dw_ref, dw_vir) and torch.equal(db_ref, db_vir), "virtual-concat weight gradient differs"
-        # input gradient: one 512-channel buffer vs 384-channel buffer + direct q2 gradient
-        wt = torch.zeros(512, 3, 3, 256, dtype=dtype, device=dev)
-        ops.weight_transpose(w.float(), wt, 256, 9, 512, 256)
-        d_full = ops.Act(torch.empty(B, H, W, 512, dtype=dtype, device=dev), 512)
-        ops.conv_forward(dy, wt, 512, 3, 3, 1, 1, mode=1, out_hw=(H, W), cin=256, out=d_full)
-        d_rest = ops.Act(torch.empty(B, H, W, 384, dtype=dtype, device=dev), 384)
-        g_q2 = ops.Act(torch.empty(B, H, W, 128, dtype=dtype, device=dev), 128)
-        ops.conv_forward(dy, wt, 512, 3, 3, 1, 1, mode=1, out_hw=(H, W), cin=256, out=d_rest, split=(g_q2, 384))
-        assert torch.equal(d_full.t[..., :384].contiguous().view(torch.int16), d_rest.t.view(torch.int16))
-        assert torch.equal(d_full.t[..., 384:].contiguous().view(torch.int16), g_q2.t.view(torch.int16))
     if dtype != torch.bfloat16:
         return
     m = get_model(50, dtype)
@@ -503,47 +414,6 @@ def test_virtual_concat_equals_the_materialised_concatenation(dtype):
     assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), "virtual concatenation changed the training step"
     report("virtual concatenation (conv2 of the keypoint head): forward / weight gradient / input gradient bit-identical to the "
            "materialised 512-channel tensor; whole keypoint step bit-identical")
-
-
-# ------------------------------------------------------------------------------------------------ ReLU backward in the dgrad epilogue
-@pytest.mark.parametrize("dtype,pyramid", [(torch.bfloat16, True), (torch.float32, True), (torch.bfloat16, False)])
-def test_relu_backward_in_the_producing_dgrad_epilogue(dtype, pyramid):
-    """relu(conv(.)) layers (the RetinaNet towers posenet.py:48-66,91-109 and conv2 :313): the gradient that reaches such a layer
-    is masked by the input-gradient launch that produces it (MpnConvParams.relu_y / seg_ry) instead of a separate relu_backward
-    pass.  Same predicate on the same values: loss and every gradient of a `train_both` step bit-identical with the fusion on and
-    off, for the one-launch-per-pyramid towers and for the per-level launches."""
-    from multiposenet.pytorch_amd.network.posenet import poseNet
-    from multiposenet.pytorch_amd import synthetic as weightgen
-    m = get_model(50, dtype)
-    for p in m.prn.parameters():
-        p.requires_grad = False
-    m.train()
-    Bn, S = 2, 128
-    img = t(weightgen.gen_images(820, Bn, S, S)).cuda()
-    heat, wgt = (t(a).cuda() for a in weightgen.gen_keypoint_gt(821, Bn, S // 4, S // 4))
-    anno = t(weightgen.gen_boxes_gt(822, Bn, S)).cuda()
-    bn_state = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
-    eng = m._engine
-    old = (eng.fuse_relu_bwd, eng.pyramid_towers)
-    outs = []
-    try:
-        eng.pyramid_towers = pyramid
-        for on in (False, True):
-            eng.fuse_relu_bwd = on
-            m.load_state_dict(bn_state, strict=False)
-            m._arena.ensure_grads()
-            m._arena.grad_flat.zero_()
-            pred, saved = m([img, "train_both"])
-            loss, _ = poseNet.build_loss(saved, "train_both", heat, wgt, anno)
-            loss.backward()
-            torch.cuda.synchronize()
-            outs.append((loss.detach().clone(), m._arena.grad_flat.clone()))
-    finally:
-        eng.fuse_relu_bwd, eng.pyramid_towers = old
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "fused ReLU backward changed the gradients"
-    w = m.regressionModel.conv2.weight
-    assert float(w.grad.abs().max()) > 0
-    report("ReLU backward fused into the producing dgrad (%s, %s towers): train_both step bit-identical" % (str(dtype), "pyramid" if pyramid else "per-level"))
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE config 5 end to end
@@ -681,53 +551,3 @@ def test_pre_nms_top_k_cap_equals_the_oracle_on_the_best_k_candidates():
            % (K, B, counts, K, call("mpn_nms_batched_workspace_bytes", B, nmax) // call("mpn_nms_batched_workspace_bytes", B, K)))
 
 
-@pytest.mark.parametrize("dtype,size", [(torch.bfloat16, 480), (torch.float32, 384)])
-def test_bn_finalize_inside_the_bn_act_launch_is_bit_identical(dtype, size):
-    """mpn_bn_act_finalize_forward: the first ceil(C/4) blocks of the bn_act grid finalize the batch statistics (the arithmetic of
-    mpn_bn_finalize_train), the rest wait on a flag word.  Same training step with the fused launch on and off: loss, gradient arena
-    and running statistics bit-identical; the separate finalize launches of the forward pass are gone; tensors too small for the
-    grid to hold the finalizing blocks fall back to the two launches."""
-    from multiposenet.pytorch_amd.network.posenet import poseNet
-    from multiposenet.pytorch_amd import _lib, ops
-    import multiposenet.pytorch_amd.ops as ops_mod
-    from test_round2_gpu import _train_setup
-    m, inputs, gts = _train_setup(50, dtype, 2, size, seed=171)
-    orig = _lib.call
-    calls = []
-
-    def counting(name, *a):
-        if name in calls[-1]:
-            calls[-1][name] += 1
-        return orig(name, *a)
-    ops_mod.call = counting
-    res = []
-    bn0 = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
-    try:
-        for fused in (False, True):
-            calls.append({"mpn_bn_finalize_train": 0, "mpn_bn_act_finalize_forward": 0, "mpn_bn_act_forward": 0})
-            m._engine.fuse_bn_act_finalize = fused
-            m.load_state_dict(bn0, strict=False)
-            m._arena.ensure_grads()
-            m._arena.grad_flat.zero_()
-            pred, saved = m(*inputs)
-            loss, log = poseNet.build_loss(saved, *gts)
-            loss.backward()
-            torch.cuda.synchronize()
-            res.append((loss.detach().clone(), m._arena.grad_flat.clone(),
-                        {k: v.clone() for k, v in m.state_dict().items() if "running_" in k}))
-    finally:
-        ops_mod.call = orig
-        m._engine.fuse_bn_act_finalize = False
-    (l0, g0, r0), (l1, g1, r1) = res
-    assert torch.equal(l0, l1) and torch.equal(g0, g1), "fused finalize + bn_act changed the step"
-    assert all(torch.equal(r0[k], r1[k]) for k in r0)
-    assert calls[0]["mpn_bn_act_finalize_forward"] == 0 and calls[1]["mpn_bn_act_finalize_forward"] > 10
-    assert calls[1]["mpn_bn_finalize_train"] < calls[0]["mpn_bn_finalize_train"]
-    assert calls[1]["mpn_bn_finalize_train"] + calls[1]["mpn_bn_act_finalize_forward"] == calls[0]["mpn_bn_finalize_train"]
-    # a tensor whose bn_act grid is smaller than ceil(C/4) blocks is refused
-    tiny = ops.Act(torch.zeros(1, 2, 2, 2048, device="cuda", dtype=dtype), 2048)
-    assert ops.bn_act_finalize(tiny, torch.zeros(1, 2048, 2, device="cuda"), torch.ones(2048, device="cuda"), torch.zeros(2048, device="cuda"),
-                               None, None, 0.1, 1e-5, True, torch.zeros(1, dtype=torch.int32, device="cuda").data_ptr()) is None
-    report("finalize inside bn_act (%s, R50 %dx%d B=2): %d separate finalize launches -> %d (+ %d fused), step bit-identical"
-           % (str(dtype).split(".")[1], size, size, calls[0]["mpn_bn_finalize_train"], calls[1]["mpn_bn_finalize_train"],
-              calls[1]["mpn_bn_act_finalize_forward"]))

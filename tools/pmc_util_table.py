@@ -2,7 +2,7 @@
 """Per-kernel MFMA / LDS utilisation table from the raw counter dump of tools/gpu_pmc_util.sh (tools/pmc_generic.py lines).
 MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES): rocprofv3 reports one value per shader engine (32 per launch on
 MI355X: 8 XCDs x 4), SQ_BUSY_CYCLES counts that engine's busy cycles once, the MFMA counter sums over its 8 CUs x 4 SIMDs (check:
-conv_pw_kernel 256->1024 @30x30 reads 460 800 per engine = 921 600 wave-level MFMAs x 16 cycles / 32 engines); LDS conflict share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE."""
+the (removed) pixel-resident 1x1 kernel at 256->1024 @30x30 reads 460 800 per engine = 921 600 wave-level MFMAs x 16 cycles / 32 engines); LDS conflict share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE."""
 import collections
 import re
 import sys
