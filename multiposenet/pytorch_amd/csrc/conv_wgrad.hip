@@ -768,7 +768,12 @@ extern "C" int mpn_conv_wgrad_chunks(const MpnWgradParams* p) {
     const long P = wgrad_total_pixels(*p);
     static const long target = getenv("MPN_WGRAD_TARGET") ? atol(getenv("MPN_WGRAD_TARGET")) : kWgradTarget;
     static const long minpix = getenv("MPN_WGRAD_MINPIX") ? atol(getenv("MPN_WGRAD_MINPIX")) : 512;
-    long want = (target + tiles - 1) / tiles;          // ~2 workgroups per CU: with the DMA ring long slices run near peak and partial-sum traffic dominates
+    // ~2 workgroups per CU (long slices run near peak, partial-sum traffic dominates beyond) and NEVER one more than that: rounding the
+    // slice count up put 540 workgroups on the 512 slots of the 3x3 256-channel layers — the 28 that share a CU three ways finish last,
+    // and in isolation the launch takes 15 - 20 % longer (3x3 256->256 @30x30 64 -> 53 us, @60x60 195 -> 161, 512->256 @120x120
+    // 1 374 -> 1 216; in the step, where the other stream fills the tail, neutral: profiles/r04_kloop_phase_profile.txt).  MPN_WGRAD_CEIL=1: the old rounding
+    static const bool round_up = getenv("MPN_WGRAD_CEIL") && atoi(getenv("MPN_WGRAD_CEIL"));
+    long want = round_up ? (target + tiles - 1) / tiles : target / tiles;
     const long maxc = (P + minpix - 1) / minpix;       // keep >= 512 pixels per slice
     if (want > maxc) want = maxc;
     if (want < 1) want = 1;
