@@ -22,6 +22,8 @@ DataParallel), computes its local-mean loss, and only gradients cross xGMI:
 Equal shard sizes => the average of local-mean gradients equals the gradient of the global mean
 (SURVEY.md 8e).  Parameters and BN buffers are broadcast from rank 0 once at attach time.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -161,8 +163,13 @@ def broadcast_state(model, process_group=None, src=0):
             bcast(m.running_var)
 
 
-def attach(model, process_group=None, bucket_mb=32.0, broadcast=True):
-    """Turn ``model`` (a poseNet already on its device) into a data-parallel replica."""
+def attach(model, process_group=None, bucket_mb=None, broadcast=True):
+    """Turn ``model`` (a poseNet already on its device) into a data-parallel replica.
+
+    ``bucket_mb`` defaults to ``MPN_BUCKET_MB`` (32): smaller buckets shorten the tail that cannot
+    overlap backward and add collective launches."""
+    if bucket_mb is None:
+        bucket_mb = float(os.environ.get("MPN_BUCKET_MB", "32"))
     if not dist.is_initialized():
         raise RuntimeError("torch.distributed is not initialised")
     if broadcast:
