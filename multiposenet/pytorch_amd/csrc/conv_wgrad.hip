@@ -352,7 +352,11 @@ __device__ __forceinline__ const void* rfl_ptr(const void* q) {
 // fragment reads + 16 MFMAs (256 cycles of matrix pipe).  Issuing the DMA between the MFMAs instead (built, measured, removed) moves
 // the stalls into the MFMA phase and leaves the k-step at ~920 cycles: the loop is bound by the texture path's ~45 B/clk, i.e. by the
 // tile's 64 FLOP per DMA byte, not by latency (the ring covers it) or by the wave's instruction order.
-template <typename T, int TM, int TN, bool SEG, bool PROF = false>
+// LIN (round 4): stride-1 "same" convolutions over a dense x (the launcher checks: wgrad_lin_ok) read x at pixel + tap offset — LINEAR in the
+// output pixel.  The tap offset moves into the buffer descriptor's base, the k-step advance into the scalar offset, and what is left per DMA
+// instruction is the halo predicate on incrementally tracked (ho, wo) (nothing at all for 1x1): ~35 VALU instructions per k-step and wave
+// instead of ~65 with ten quarter-rate v_mul_lo_u32 (the general gather: strided / virtually concatenated / up-sampled operands).
+template <typename T, int TM, int TN, bool SEG, bool PROF = false, bool LIN = false>
 __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, long chunk_pixels, unsigned long long* prof = nullptr) {
     const bool ablate_stores = (chunk_pixels >> 62) & 1;     // MPN_WGRAD_ABLATE=2 (tools only): how much do the partial stores cost?
     chunk_pixels &= ~(1L << 62);
@@ -405,7 +409,13 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, lo
         p.x_sB = (int64_t)(p.H >> vsh) * p.x_sH;
     }
 
-    const i32x4_t rsrc_x = make_rsrc(p.x, (unsigned)((long)p.B * p.x_sB * 2));
+    const int dr = r - p.pad, dsx = s - p.pad;                       // LIN: tap offset in lines / pixels
+    const long tap_bytes = LIN ? ((long)dr * p.W + dsx) * p.x_sW * 2 : 0;      // base moves by the tap; a valid (ho + dr, wo + dsx) never reads before x
+    long x_bytes_l = (long)p.B * p.x_sB * 2 - tap_bytes;
+    if (x_bytes_l < 0) x_bytes_l = 0;
+    if (x_bytes_l > 0x7fffffffL) x_bytes_l = 0x7fffffffL;
+    const i32x4_t rsrc_x = make_rsrc((const char*)p.x + tap_bytes, (unsigned)x_bytes_l);
+    const bool halo = LIN && (p.R > 1 || p.S > 1 || p.pad != 0);     // uniform: 1x1 needs no predicate and no pixel digits
     const i32x4_t rsrc_dy = make_rsrc(p.dy, (unsigned)((k_end > k_begin ? k_end : 0) * (long)p.dy_sP * 2));
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
@@ -419,7 +429,10 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, lo
         const int chan = ((lane % (ROWA / 16)) ^ dma_swz<ROWA>(row)) * 8;
         a_chan[q] = m0 + chan;
         a_on[q] = (m0 + chan) < p.Cin;
-        long pix = k_begin + row; if (pix >= P) pix = P - 1;     // beyond-the-end rows meet zero dY rows
+        long pix = k_begin + row;
+        if (LIN) {           // a_chan holds the lane's byte offset from the tap-shifted base (rows past the end run out of the descriptor or meet zero dY rows)
+            a_chan[q] = a_on[q] ? (int)(unsigned)((pix * p.x_sW + m0 + chan) * 2) : (int)DMA_OOB;
+        } else if (pix >= P) pix = P - 1;     // beyond-the-end rows meet zero dY rows
         a_px[q].init(pix, p.Ho, p.Wo);
     }
 #pragma unroll
@@ -430,6 +443,14 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, lo
     }
     const unsigned b_step = (unsigned)__builtin_amdgcn_readfirstlane((int)(KP * p.dy_sP * 2));
     unsigned b_soff = 0;
+    const unsigned a_step = (unsigned)__builtin_amdgcn_readfirstlane((int)(KP * p.x_sW * 2));
+    unsigned a_soff = 0;
+    unsigned a_sel[QA];                  // LIN: the lane's offset or the out-of-range marker for the k-step about to be queued
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+        const bool ok = !halo || ((unsigned)(a_px[q].ho + dr) < (unsigned)p.H && (unsigned)(a_px[q].wo + dsx) < (unsigned)p.W);
+        a_sel[q] = ok ? (unsigned)a_chan[q] : DMA_OOB;
+    }
     const int adv_t = KP / p.Wo, adv_w = KP - adv_t * p.Wo, adv_b = adv_t / p.Ho, adv_h = adv_t - adv_b * p.Ho;
 
     f32x4_t acc[MM][MN];
@@ -440,6 +461,12 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, lo
 
     auto issue = [&](unsigned stage) {       // queue one k-step (QA + QB DMA instructions per wave) into ring slot `stage`
         const unsigned st = lds_base + stage * STAGE_BYTES;
+        if constexpr (LIN) {
+#pragma unroll
+            for (int q = 0; q < QA; ++q)
+                lds_dma16(a_sel[q], rsrc_x, a_soff, __builtin_amdgcn_readfirstlane(st + (wave_u * QA + q) * 1024u));
+            a_soff += a_step;
+        } else
 #pragma unroll
         for (int q = 0; q < QA; ++q) {
             const int hi = a_px[q].ho * p.stride - p.pad + r, wi = a_px[q].wo * p.stride - p.pad + s;
@@ -453,6 +480,16 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, lo
         for (int q = 0; q < QB; ++q)
             lds_dma16(b_voff[q], rsrc_dy, b_soff, __builtin_amdgcn_readfirstlane(st + A_BYTES + (wave_u * QB + q) * 1024u));
         b_soff += b_step;
+        if constexpr (LIN) {
+            if (halo) {      // the NEXT k-step's halo predicate, computed behind this one's queue (it runs under the MFMA phase)
+#pragma unroll
+                for (int q = 0; q < QA; ++q) {
+                    a_px[q].advance_digits(0, adv_h, adv_w, p.Ho, p.Wo);
+                    const bool ok = (unsigned)(a_px[q].ho + dr) < (unsigned)p.H && (unsigned)(a_px[q].wo + dsx) < (unsigned)p.W;
+                    a_sel[q] = ok ? (unsigned)a_chan[q] : DMA_OOB;
+                }
+            }
+        }
     };
 
     // fragment gather: lane l -> rows k = 8*(l>>4) + 4*h + ((l&15)>>2), 8-byte piece (l&3) of the 16-channel block
@@ -574,16 +611,28 @@ __global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_prof_ker
     conv_wgrad_dma_body<bf16_t, TM, TN, false, true>(p, chunk_pixels, prof);
 }
 template <int TM, int TN>
+__global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_lin_kernel(const MpnWgradParams p, long chunk_pixels) {
+    conv_wgrad_dma_body<bf16_t, TM, TN, false, false, true>(p, chunk_pixels);
+}
+template <int TM, int TN>
+__global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_lin_f16_kernel(const MpnWgradParams p, long chunk_pixels) {
+    conv_wgrad_dma_body<f16_t, TM, TN, false, false, true>(p, chunk_pixels);
+}
+template <int TM, int TN>
+__global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_lin_prof_kernel(const MpnWgradParams p, long chunk_pixels, unsigned long long* prof) {
+    conv_wgrad_dma_body<bf16_t, TM, TN, false, true, true>(p, chunk_pixels, prof);
+}
+template <int TM, int TN>
 __global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_f16_kernel(const MpnWgradParams p, long chunk_pixels) {
     conv_wgrad_dma_body<f16_t, TM, TN, false>(p, chunk_pixels);
 }
 template <int TM, int TN>
 __global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_seg_kernel(const MpnWgradParams p, long chunk_pixels) {
-    conv_wgrad_dma_body<bf16_t, TM, TN, true>(p, chunk_pixels);
+    conv_wgrad_dma_body<bf16_t, TM, TN, true, false, true>(p, chunk_pixels);     // pyramid levels are dense stride-1 "same" convolutions (mpn_conv_wgrad checks)
 }
 template <int TM, int TN>
 __global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_seg_f16_kernel(const MpnWgradParams p, long chunk_pixels) {
-    conv_wgrad_dma_body<f16_t, TM, TN, true>(p, chunk_pixels);
+    conv_wgrad_dma_body<f16_t, TM, TN, true, false, true>(p, chunk_pixels);
 }
 
 // dst[i] (+)= sum_c ws[c][i], chunks added in index order (deterministic).  (A variant that split the chunks over four
@@ -667,6 +716,13 @@ inline bool wgrad_uses_dma(const MpnWgradParams& p) {
     return (p.dtype == MPN_BF16 || p.dtype == MPN_F16) && use_dma && small && p.Cin % 8 == 0;
 }
 
+// LIN instantiations (linear x addressing): stride-1 convolutions whose output has the input's extent, over a dense x, no virtual concatenation
+inline bool wgrad_lin_ok(const MpnWgradParams& p) {
+    static const bool on = !(getenv("MPN_WGRAD_LIN") && !atoi(getenv("MPN_WGRAD_LIN")));
+    if (p.nseg > 0) return true;
+    return on && p.kseg_n == 0 && p.stride == 1 && p.Ho == p.H && p.Wo == p.W && p.x_sH == (int64_t)p.W * p.x_sW && p.x_sB == (int64_t)p.H * p.x_sH;
+}
+
 constexpr long kWgradTarget = 512;       // workgroups per launch (~2 per CU): long slices, little partial-sum traffic
 
 inline void wgrad_tiles(const MpnWgradParams& p, int& tm, int& tn) {
@@ -712,8 +768,13 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st, bool reduce = true) {
         else if (tm == 128) hipLaunchKernelGGL((KERNEL<128, 64>), g, blk, 0, st, p, chunk_pixels);                       \
         else if (tn == 128) hipLaunchKernelGGL((KERNEL<64, 128>), g, blk, 0, st, p, chunk_pixels);                       \
         else hipLaunchKernelGGL((KERNEL<64, 64>), g, blk, 0, st, p, chunk_pixels)
+        const bool lin = wgrad_lin_ok(p);
         if (g_wgrad_prof && p.nseg == 0 && p.dtype == MPN_BF16 && tm == 128 && tn == 128) {
-            hipLaunchKernelGGL((conv_wgrad_dma_prof_kernel<128, 128>), g, blk, 0, st, p, chunk_pixels, g_wgrad_prof);
+            if (lin) hipLaunchKernelGGL((conv_wgrad_dma_lin_prof_kernel<128, 128>), g, blk, 0, st, p, chunk_pixels, g_wgrad_prof);
+            else hipLaunchKernelGGL((conv_wgrad_dma_prof_kernel<128, 128>), g, blk, 0, st, p, chunk_pixels, g_wgrad_prof);
+        } else if (p.nseg == 0 && lin) {
+            if (p.dtype == MPN_F16) { MPN_WGRAD_DMA_LAUNCH(conv_wgrad_dma_lin_f16_kernel); }
+            else { MPN_WGRAD_DMA_LAUNCH(conv_wgrad_dma_lin_kernel); }
         } else if (p.nseg > 0) {
             if (p.dtype == MPN_F16) { MPN_WGRAD_DMA_LAUNCH(conv_wgrad_dma_seg_f16_kernel); }
             else { MPN_WGRAD_DMA_LAUNCH(conv_wgrad_dma_seg_kernel); }
