@@ -184,7 +184,8 @@ int mpn_conv_wgrad(const MpnWgradParams* p, void* stream);
 /* first stage only (chunks > 1): the per-slice partial gradients go to ws and the caller finishes with
  * mpn_reduce_partials(ws, chunks, Cout*R*S*Cin, dw, 1, stream) — lets a profiler bracket the MFMA kernel alone */
 int mpn_conv_wgrad_partials(const MpnWgradParams* p, void* stream);
-/* which kernel mpn_conv_wgrad launches for p: (tile_cin << 16) | (tile_cout << 4) | uses_lds_dma */
+/* which kernel mpn_conv_wgrad launches for p: (tile_cin << 16) | (tile_cout << 4) | linear_x_addressing << 1 | uses_lds_dma
+ * (bit 1: the instantiation for stride-1 same-extent convolutions over a dense x — halo predicate only, no per-lane address arithmetic) */
 int mpn_conv_wgrad_kernel_id(const MpnWgradParams* p);
 
 /* dst[i] (+)= sum_{c<chunks} ws[c*n + i]  — deterministic second stage of split reductions */

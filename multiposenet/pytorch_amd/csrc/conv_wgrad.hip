@@ -886,7 +886,8 @@ extern "C" int mpn_conv_wgrad_kernel_id(const MpnWgradParams* p) {
     if (!p) return MPN_E_BADARG;
     int tm, tn;
     wgrad_tiles(*p, tm, tn);
-    return (tm << 16) | (tn << 4) | (wgrad_uses_dma(*p) ? 1 : 0);
+    const bool dma = wgrad_uses_dma(*p);
+    return (tm << 16) | (tn << 4) | (dma && p->nseg == 0 && wgrad_lin_ok(*p) ? 2 : 0) | (dma ? 1 : 0);      // bit 1: the linear-addressing instantiation
 }
 
 extern "C" int mpn_reduce_partials(const float* ws, int chunks, int64_t n, float* dst, int accumulate, void* stream) {

@@ -378,7 +378,7 @@ def conv_wgrad_cat(srcs, H, W, dy, dw, Cout, db=None):
         kid = call("mpn_conv_wgrad_kernel_id", ctypes.byref(p))
         e0 = KERNEL_EVENTS.begin()
         call("mpn_conv_wgrad_partials" if chunks > 1 else "mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
-        name = "conv_wgrad_dma%s_kernel<%d, %d>" % ("_f16" if dt == torch.float16 else "", kid >> 16, (kid >> 4) & 0xfff)
+        name = "conv_wgrad_dma%s%s_kernel<%d, %d>" % ("_lin" if (kid & 2) else "", "_f16" if dt == torch.float16 else "", kid >> 16, (kid >> 4) & 0xfff)
         if KERNEL_EVENTS.detail:
             name = "wgrad 3x3 %d->%d @%dx%d s1 virtual-cat chunks=%d|%d" % (Cin, Cout, H, W, chunks, sum(a.t.numel() for a in srcs) * 2 + dy.t.numel() * 2)
         KERNEL_EVENTS.end(name, 2.0 * x0.B * H * W * Cout * 9 * Cin, e0)
@@ -567,7 +567,7 @@ def conv_wgrad(x, dy, dw, Cout, R, S, stride, pad, cin=None, x_geom=None, db=Non
         e0 = KERNEL_EVENTS.begin()
         call("mpn_conv_wgrad_partials" if chunks > 1 else "mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
         dts = dtype_name(dt)
-        name = ("conv_wgrad_dma%s_kernel<%d, %d>" % ("_f16" if dt == torch.float16 else "", kid >> 16, (kid >> 4) & 0xfff) if (kid & 1)
+        name = ("conv_wgrad_dma%s%s_kernel<%d, %d>" % ("_lin" if (kid & 2) else "", "_f16" if dt == torch.float16 else "", kid >> 16, (kid >> 4) & 0xfff) if (kid & 1)
                 else "conv_wgrad_kernel<%s, %d, %d>" % (dts, kid >> 16, (kid >> 4) & 0xfff))
         if KERNEL_EVENTS.detail:
             es = 2 if is16(dt) else 4

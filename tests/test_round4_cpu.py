@@ -109,6 +109,7 @@ def _hot_kernels():
     hot.append((mangled("conv_igemm_s3_kernel", "t", 256, 128, False, True, True, False), 2, 73728, 8))
     for tm, tn, lds in ((128, 128, 49152), (128, 64, 36864), (64, 128, 36864), (64, 64, 24576)):
         hot.append((mangled("conv_wgrad_dma_kernel", tm, tn), 3, lds))
+        hot.append((mangled("conv_wgrad_dma_lin_kernel", tm, tn), 3, lds))      # the instantiation nearly every launch of the step takes (round 4)
     hot.append((mangled("conv_wgrad_dma_seg_kernel", 128, 128), 3, 49152))
     for k, w in (("bn_act_kernel", 8), ("bn_act_acc_kernel", 8), ("bn_bwd_apply_kernel", 5), ("relu_bwd_kernel", 8), ("maxpool_fwd_kernel", 4)):
         hot.append((mangled(k, "t"), w, None))
