@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 4, call AC: s_setprio 1 over the MFMA cluster of every k-step (all three DMA kernels; library built with -DMPN_MFMA_PRIO=1) + the new LIN parity test
+# round 4, calls AC / AD: wave priority experiments (library built with -DMPN_MFMA_PRIO=1: over the MFMA cluster; -DMPN_DMA_PRIO=1: while queueing DMA)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/r4ac; mkdir -p $O
 L=multiposenet/pytorch_amd/libmpn_hip.so
-timeout 900 python -m pytest tests/test_round4_gpu.py tests/test_kernels_gpu.py -q -x -m gpu -p no:cacheprovider -k "linear or partials" > $O/tests_lin.log 2>&1; tail -2 $O/tests_lin.log
+
 cp $L /tmp/base.so
 ab() {  # label lib
   cp $2 $L
