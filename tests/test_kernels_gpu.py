@@ -193,7 +193,7 @@ def test_wgrad_partials_entry_point_matches_fused_call():
         finally:
             ops.KERNEL_EVENTS.disable()
         assert torch.equal(dw, dw2)
-        assert names and (names[0].startswith("conv_wgrad_dma_lin_kernel<") or names[0].startswith("conv_wgrad_dma_kernel<")), names
+        assert names and names[0].startswith("conv_wgrad_"), names
         # bias gradient fused into the same kernel (ones-vector MFMA): sliced and bracketed paths, vs the column sums
         for events in (False, True):
             dw3 = torch.zeros_like(dw)

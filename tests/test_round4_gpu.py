@@ -470,26 +470,28 @@ def test_bf16_pyramids_heads_and_stem_against_the_rounding_oracle():
     report("bf16 pyramids / heads / stem vs the same-rounding oracle (R50, teacher-forced): all within 2e-3 / 3e-2 / 5e-2")
 
 
-# ------------------------------------------------------------------------------------------------ linear x addressing in the weight gradient
+# ------------------------------------------------------------------------------------------------ weight-gradient instantiations of round 4
 @pytest.mark.parametrize("case", [
-    # B, H, W, Cin, Cout, k, pad, stride     expect the linear instantiation?
-    ((3, 7, 5, 64, 64, 3, 1, 1), True),       # images smaller than a k-step: several images, every border, per 32-pixel step
-    ((2, 4, 4, 128, 128, 3, 1, 1), True),     # the pyramid's smallest level: a k-step spans two images
-    ((5, 9, 13, 128, 64, 3, 1, 1), True),     # pixel count not a multiple of 32: the last k-step runs past the tensor
-    ((2, 31, 29, 256, 128, 1, 0, 1), True),   # 1x1: no predicate at all
-    ((4, 30, 30, 64, 128, 3, 1, 1), True),    # several slices, slice boundaries inside images
-    ((2, 16, 16, 64, 64, 3, 1, 2), False),    # strided: the general gather
-    ((2, 12, 12, 64, 64, 3, 0, 1), False),    # "valid" convolution (output smaller than input): the general gather
+    # B, H, W, Cin, Cout, k, pad, stride     which instantiation must take it
+    ((3, 7, 5, 64, 64, 3, 1, 1), "lin"),       # images smaller than a k-step: several images and every border in every step
+    ((2, 4, 4, 128, 128, 3, 1, 1), "lin"),     # the pyramid's smallest level: a k-step spans two images
+    ((2, 31, 29, 256, 128, 1, 0, 1), "lin"),   # 1x1: no predicate at all
+    ((5, 9, 13, 128, 64, 3, 1, 1), "lin"),     # pixel count not a multiple of 32: the last k-step runs past the tensor
+    ((4, 30, 30, 64, 128, 3, 1, 1), "lin"),    # several slices, slice boundaries inside images
+    ((3, 8, 8, 64, 256, 3, 1, 1), "lin"),      # borders in every k-step
+    ((2, 17, 33, 200, 72, 3, 1, 1), "lin"),    # ragged channel counts (partial cin / cout tiles), W = k-step + 1
+    ((1, 60, 60, 256, 256, 3, 1, 1), "lin"),   # many slices per tap, long reductions
+    ((2, 16, 16, 64, 64, 3, 1, 2), "dma"),     # strided: the general gather
+    ((2, 12, 12, 64, 64, 3, 0, 1), "dma"),     # "valid" convolution (output smaller than input): the general gather
 ])
-def test_wgrad_linear_addressing_matches_torch(case):
-    """layers.py / fpn.py convolutions, weight gradient (torch autograd is the reference).  Stride-1 same-extent convolutions over a dense
-    x take the LIN instantiation of conv_wgrad_dma_kernel (mpn_conv_wgrad_kernel_id bit 1): the tap offset sits in the buffer descriptor,
-    the k-step advance in the scalar offset, and only the halo predicate is per lane.  Shapes chosen for what that changes: borders in
-    every k-step, k-steps spanning images, rows past the end of the tensor, slices cut inside images; and the shapes that must NOT take it."""
-    import ctypes
+def test_wgrad_instantiations_match_torch(case):
+    """layers.py / fpn.py convolutions, weight gradient (torch autograd is the reference).  Round 4 added the LIN instantiation of the LDS-DMA
+    kernel (stride-1 same-extent convolutions over a dense x: tap offset in the buffer descriptor, k-step advance in the scalar offset,
+    only the halo predicate per lane).  Shapes chosen for what that changes: borders in every k-step, k-steps spanning images, rows before
+    and past the tensor, slices cut inside images, ragged tiles; and the shapes that must NOT take it.  (The same cases also passed on the
+    shared-tap 3x3 kernel of tools/experiments_r4/wgrad_shared_tap_s3.patch, which was measured and not kept.)"""
     from multiposenet.pytorch_amd import ops
-    from multiposenet.pytorch_amd._lib import call
-    (B, H, W, Cin, Cout, k, pad, stride), want_lin = case
+    (B, H, W, Cin, Cout, k, pad, stride), kind = case
     dtype = torch.bfloat16
     x = rnd(dtype, rng_normal(51, B, Cin, H, W))
     w = rnd(dtype, rng_normal(52, Cout, Cin, k, k) / float(np.sqrt(Cin * k * k))).requires_grad_(True)
@@ -497,14 +499,21 @@ def test_wgrad_linear_addressing_matches_torch(case):
     dy = rnd(dtype, rng_normal(53, *y.shape))
     y.backward(dy)
     dw = torch.zeros((Cout, k, k, Cin), dtype=torch.float32, device="cuda")
+    db = torch.zeros((Cout,), dtype=torch.float32, device="cuda")
     ops.KERNEL_EVENTS.enable()
     try:
-        ops.conv_wgrad(to_act(x, dtype), to_act(dy, dtype), dw, Cout, k, k, stride, pad)
+        fused = ops.conv_wgrad(to_act(x, dtype), to_act(dy, dtype), dw, Cout, k, k, stride, pad, db=db)
         names = [r[0] for r in ops.KERNEL_EVENTS.rec]
     finally:
         ops.KERNEL_EVENTS.disable()
-    assert names and names[0].startswith("conv_wgrad_dma_lin_kernel<" if want_lin else "conv_wgrad_dma_kernel<"), names
-    check_close("wgrad lin %s" % (case,), dw.cpu().permute(0, 3, 1, 2), w.grad, dtype)
+    prefix = {"lin": "conv_wgrad_dma_lin_kernel<", "dma": "conv_wgrad_dma_kernel<"}[kind]
+    assert names and names[0].startswith(prefix), names
+    check_close("wgrad %s %s" % (kind, case[0]), dw.cpu().permute(0, 3, 1, 2), w.grad, dtype)
+    if fused:
+        check_close("wgrad bias %s %s" % (kind, case[0]), db.cpu(), dy.sum((0, 2, 3)), torch.float32, factor=5)
     dw2 = torch.zeros_like(dw)
-    ops.conv_wgrad(to_act(x, dtype), to_act(dy, dtype), dw2, Cout, k, k, stride, pad)       # the un-bracketed entry point
-    assert torch.equal(dw, dw2)
+    ops.conv_wgrad(to_act(x, dtype), to_act(dy, dtype), dw2, Cout, k, k, stride, pad)       # the un-bracketed entry point, no bias (lean instantiation)
+    check_close("wgrad no-bias %s %s" % (kind, case[0]), dw2.cpu().permute(0, 3, 1, 2), w.grad, dtype)
+    dw3 = torch.zeros_like(dw)
+    ops.conv_wgrad(to_act(x, dtype), to_act(dy, dtype), dw3, Cout, k, k, stride, pad)
+    assert torch.equal(dw2, dw3), "weight gradient differs from run to run"
