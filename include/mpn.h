@@ -123,6 +123,18 @@ typedef struct MpnConvParams {
      * fin_counters.  Range: |sum| < 2^(63-28) = 3.4e10, sum^2 < 2^(63-20) = 8.8e12 (an rms of 2 000 over 2 M pixels); resolution
      * per tile 3.7e-9 / 9.5e-7, i.e. at most 7.5e-9 on E[x^2] — three orders below the eps = 1e-5 that the variance is added to. */
     int32_t stats_atomic;
+    /* Parity classes of a stride-2 input gradient (y_step == 2; round 4).  dx[h][w] of a 3x3 / stride 2 / pad 1 convolution only receives
+     * the taps r = (h + 1) mod 2 (+ 2), s likewise: of the nine taps 1, 2, 2 or 4 are live, depending on the parities (a, c) of (h, w) — the
+     * gather form (mode 1, stride 2) multiplies the other 6.75 of 9 with zeros.  One launch per class computes
+     *   dx[b][2 i + a][2 j + c] = sum_{t_r <= a, t_s <= c} dy[b][i + t_r][j + t_s] . W[a + 1 - 2 t_r][c + 1 - 2 t_s]
+     * as a FORWARD gather (mode 0, stride 1, pad 0, R = 1 + a, S = 1 + c) over dy whose output pixel (i, j) is stored at
+     * (y_step i + y_oh, y_step j + y_ow) of the dense [B][y_H][y_W] tensor y (and of every output-shaped operand: accumulate, bnb_y,
+     * bnb_mask), and whose filter tap (t_r, t_s) is tap wtap0 + t_r wtap_dr + t_s wtap_ds of a weight tensor with w_taps taps per output
+     * channel ([Cout][w_taps][Cin]).  Ho, Wo = the class grid (ceil((y_H - a) / 2), ceil((y_W - c) / 2)); rows of dy past its end read zeros.
+     * 16-bit operands, extended epilogue; not combined with nseg, kseg_n, res, fin_counters, stats.  (torch.nn.Conv2d(stride=2) backward:
+     * network/layers.py, the first Bottleneck of layer2-4; posenet.py P6 / P7.)                                                        */
+    int32_t y_step, y_oh, y_ow, y_H, y_W;
+    int32_t w_taps, wtap0, wtap_dr, wtap_ds;
 } MpnConvParams;
 #define MPN_STAT_SUM_FRAC_BITS 28
 #define MPN_STAT_SQ_FRAC_BITS 20

@@ -44,6 +44,8 @@ class ConvParams(ctypes.Structure):
         ("fin_rv", ctypes.c_void_p), ("fin_out", ctypes.c_void_p), ("fin_dgamma", ctypes.c_void_p), ("fin_dbeta", ctypes.c_void_p),
         ("fin_count", ctypes.c_double), ("fin_momentum", ctypes.c_float), ("fin_eps", ctypes.c_float), ("fin_train", ctypes.c_int32),
         ("stats_atomic", ctypes.c_int32),
+        ("y_step", ctypes.c_int32), ("y_oh", ctypes.c_int32), ("y_ow", ctypes.c_int32), ("y_H", ctypes.c_int32), ("y_W", ctypes.c_int32),
+        ("w_taps", ctypes.c_int32), ("wtap0", ctypes.c_int32), ("wtap_dr", ctypes.c_int32), ("wtap_ds", ctypes.c_int32),
     ]
 
 

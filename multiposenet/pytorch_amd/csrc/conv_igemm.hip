@@ -257,7 +257,7 @@ __device__ __forceinline__ void fin_last_arriver(const MpnConvParams& p, int c0,
 // instantiation serves everything the training / inference steps launch by default with ONE added tensor (residual, optionally
 // through mask bits, OR the previous output) and mask bits / recomputation for the statistics: with all features compiled into
 // one kernel the 128-row tile needed 80 - 97 spilled registers at its three-waves-per-SIMD budget (+3.3 ms/step, r03 trace).
-template <typename T, typename OT, int TC, int TP, bool GENERAL, bool EXT>
+template <typename T, typename OT, int TC, int TP, bool GENERAL, bool EXT, bool YSTEP = false>      // YSTEP: parity-class output (conv_igemm_kernel's extended instantiation only)
 __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&acc)[ConvCfg<T, TC, TP>::MC][ConvCfg<T, TC, TP>::MP],
                                               int c0, long p0, int wc, int wp, int lane, int tp, unsigned char* lds, const int dbg,
                                               int tc, int ntiles, const MpnConvParams& pk) {
@@ -445,6 +445,12 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
             for (int g = 0; g < G; ++g) {
                 live[g] = pix < P && ccol < p.Cout_store && !(dbg & 128);
                 yo[g] = b * (unsigned)p.y_sB + rem * (unsigned)p.y_sP + (unsigned)ccol;
+                unsigned mpix = pix;                             // pixel index into the output-shaped mask tensors
+                if (YSTEP && pk.y_step > 1) {                      // parity-class launch (mpn.h): output pixel (i, j) lives at (step i + oh, step j + ow)
+                    const unsigned ho = rem / (unsigned)p.Wo, wo = rem - ho * (unsigned)p.Wo;
+                    mpix = (b * (unsigned)pk.y_H + ho * (unsigned)pk.y_step + (unsigned)pk.y_oh) * (unsigned)pk.y_W + wo * (unsigned)pk.y_step + (unsigned)pk.y_ow;
+                    yo[g] = mpix * (unsigned)p.y_sP + (unsigned)ccol;
+                }
                 if (GENERAL && live[g]) {
                     if (p.res_mode != 0) {
                         long ro;
@@ -456,14 +462,14 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
                             ro = (long)b * p.res_sB + (long)(rh * (unsigned)p.res_W + rw) * p.res_sP;
                         }
                         l_add[g] = *reinterpret_cast<const u32x4_t*>(Rz + ro + ccol);
-                        if (pk.res_mask) l_rm[g] = pk.res_mask[pix * (unsigned)mrow + (unsigned)(ccol / EV)];
+                        if (pk.res_mask) l_rm[g] = pk.res_mask[mpix * (unsigned)mrow + (unsigned)(ccol / EV)];
                     }
                     if (add_acc) l_add[g] = *reinterpret_cast<const u32x4_t*>(Y + yo[g]);
                     if (EXT && p.accumulate) l_acc[g] = *reinterpret_cast<const u32x4_t*>(Y + yo[g]);
                     if (bnb) {
                         l_y[g] = *reinterpret_cast<const u32x4_t*>(Ybn + yo[g]);
                         if (EXT && Zbn) l_z[g] = *reinterpret_cast<const u32x4_t*>(Zbn + yo[g]);
-                        if (Mbn) l_m[g] = Mbn[pix * (unsigned)mrow + (unsigned)(ccol / EV)];
+                        if (Mbn) l_m[g] = Mbn[mpix * (unsigned)mrow + (unsigned)(ccol / EV)];
                     }
                 }
                 pix += PPI; rem += PPI;
@@ -632,7 +638,7 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_kernel(const
     const long p0 = (long)tp * TP;
     const int c0 = tc * TC;
     constexpr unsigned TS = (unsigned)sizeof(T);
-    const long KW = (long)p.R * p.S * p.Cin;
+    const long KW = (long)(pk.w_taps > 0 ? pk.w_taps : p.R * p.S) * p.Cin;      // w_taps: a tap subset of a larger filter (mpn.h: parity classes)
     const int sh = p.stride - 1;          // dgrad supports stride 1 or 2
     // 32-bit per-lane byte offsets into buffer descriptors; the k-chunk offset rides in the scalar soffset (the
     // launcher guarantees tensor bytes + one row < 4 GB so marker + soffset cannot wrap)
@@ -700,6 +706,7 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_kernel(const
                 ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
                 b_voff[q] = ok ? b_base[q] + (unsigned)hi * sH_b + (unsigned)wi * sW_b : x_bytes;
             }
+            if (pk.w_taps > 0) klin = (pk.wtap0 + r * pk.wtap_dr + s * pk.wtap_ds) * p.Cin;      // tap (r, s) of this launch = that tap of the filter
         }
         const unsigned so_w = (unsigned)klin * TS, so_x = (unsigned)cc * TS;
         const unsigned st = lds_base + stage * C::STAGE_BYTES;
@@ -756,7 +763,7 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_kernel(const
     if (dbg & 16) { if (acc[0][0][0] == 123.456f) ((float*)p.y)[0] = 1.f; return; }   // ablation: no epilogue
     const int ntiles = (int)(gridDim.x / (unsigned)tilesC);       // pixel tiles of the launch (in-launch finalize)
     if (OUTF32) conv_epilogue<T, float, TC, TP, GENERAL, EXT>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
-    else        conv_epilogue<T, T, TC, TP, GENERAL, EXT>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
+    else        conv_epilogue<T, T, TC, TP, GENERAL, EXT, EXT>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
     if (PROF) kp.finish(nsteps, loop_end);
 }
 
@@ -1052,7 +1059,7 @@ int launch_conv_k(const MpnConvParams& p, int tc, long grid, int dbg, hipStream_
 // the extended epilogue (see conv_epilogue): only when a launch asks for one of its features
 inline bool conv_needs_ext(const MpnConvParams& p) {
     return (p.bnb_partial && p.bnb_relu && p.bnb_z && !p.bnb_mask) ||
-           (p.res_mode && p.accumulate) || p.kseg_n > 0;
+           (p.res_mode && p.accumulate) || p.kseg_n > 0 || p.y_step > 1;
 }
 
 template <typename T, bool OUTF32>
@@ -1140,10 +1147,22 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
                                       (p.stats ? p.fin_out != nullptr : true)));
     MPN_CHECK_ARG(!p.bnb_partial || (p.bnb_y && p.bnb_mean && p.bnb_invstd && !p.out_f32 && !p.nseg && !p.stats && !p.act &&
                                      (!p.bnb_relu || p.bnb_z || p.bnb_mask || (p.bnb_scale && p.bnb_shift)) &&
-                                     (!p.bnb_mask || (p.y_sB == (int64_t)p.Ho * p.Wo * p.y_sP && p.y_sP == p.Cout_store))));
+                                     (!p.bnb_mask || ((p.y_step > 1 || p.y_sB == (int64_t)p.Ho * p.Wo * p.y_sP) && p.y_sP == p.Cout_store))));
+    if (p.y_step != 0 || p.w_taps != 0) {      // parity-class launch of a strided input gradient (mpn.h)
+        MPN_CHECK_ARG(p.y_step == 2 && p.w_taps > 0 && p.dtype != MPN_F32 && !p.out_f32 && p.mode == 0 && p.stride == 1 && p.pad == 0 && !p.nseg && !p.kseg_n);
+        MPN_CHECK_ARG(!p.res_mode && !p.fin_counters && !p.stats && !p.bias && !p.scale && !p.act);
+        MPN_CHECK_ARG(p.y_oh >= 0 && p.y_oh < 2 && p.y_ow >= 0 && p.y_ow < 2 && p.R >= 1 && p.R <= 2 && p.S >= 1 && p.S <= 2);
+        MPN_CHECK_ARG(p.y_H > 0 && p.y_W > 0 && 2 * (p.Ho - 1) + p.y_oh < p.y_H && 2 * (p.Wo - 1) + p.y_ow < p.y_W);
+        MPN_CHECK_ARG(p.y_sB == (int64_t)p.y_H * p.y_W * p.y_sP && p.y_sP == p.Cout_store);
+        for (int r = 0; r < p.R; ++r)
+            for (int s = 0; s < p.S; ++s) {
+                const int t = p.wtap0 + r * p.wtap_dr + s * p.wtap_ds;
+                MPN_CHECK_ARG(t >= 0 && t < p.w_taps);
+            }
+    }
     {   // buffer descriptors address at most 4 GB per operand
         const int64_t ts = p.dtype == MPN_F32 ? 4 : 2;
-        const int64_t row = (int64_t)p.R * p.S * p.Cin * ts;
+        const int64_t row = (int64_t)(p.w_taps > 0 ? p.w_taps : p.R * p.S) * p.Cin * ts;
         int64_t xb = (int64_t)p.B * p.x_sB * ts;
         for (int l = 0; l < p.nseg; ++l) { const int64_t v = (int64_t)p.B * p.seg_H[l] * p.seg_W[l] * p.x_sW * ts; if (l == 0 || v > xb) xb = v; }
         if (xb + row >= 0xfffffff0LL || (int64_t)(p.Cout + 1) * row >= 0xfffffff0LL) return MPN_E_UNSUPPORTED;

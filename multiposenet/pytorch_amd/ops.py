@@ -398,7 +398,7 @@ def conv_out_hw(H, W, R, S, stride, pad):
 def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, res=None, res_mode=0,
                  want_stats=False, out_f32=False, out=None, accumulate=False, mode=0, out_hw=None,
                  cin=None, x_geom=None, y_geom=None, cout_store=None, needs_grad=False, tag="", bnb=None, bn_fin=None, res_mask=None,
-                 stat_acc=None):
+                 stat_acc=None, _cls=None):
     """Implicit-GEMM convolution.  x: Act.  w: compute-dtype tensor laid out [Cout][R][S][Cin].
 
     mode 0 = forward gather, mode 1 = dgrad gather (then ``out_hw`` is the input-gradient size and
@@ -407,6 +407,17 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
     """
     dev = x.t.device
     dt = x.t.dtype
+    if (DGRAD_S2_CLASSES and _cls is None and mode == 1 and stride == 2 and is16(dt) and not out_f32
+            and res is None and not want_stats and bias is None and scale is None and act == 0 and x_geom is None and y_geom is None
+            and out_hw is not None):
+        if R == 3 and S == 3 and pad == 1:
+            return _conv_dgrad_s2_classes(x, w, Cout, out_hw, cin, out, accumulate, bnb, needs_grad, tag)
+        if R == 1 and S == 1 and pad == 0 and accumulate and bnb is None and out is not None:
+            # 1x1 / stride 2 (the ResNet down-sampling shortcut): only the pixels (2 i, 2 j) of dx receive anything — one class, one tap.  Needs an
+            # existing dx to add to (the other three quarters keep what they hold) and no epilogue statistics (they would need every pixel).
+            conv_forward(x, w, Cout, 1, 1, 1, 0, out=out, accumulate=True, mode=0, out_hw=((out_hw[0] + 1) // 2, (out_hw[1] + 1) // 2), cin=cin,
+                         _cls=(0, 0, None, 0, 1))
+            return out, None
     Cin = cin if cin is not None else round_up(x.C, 32 if is16(dt) else 16)
     if x_geom is None:
         H, W = x.H, x.W
@@ -422,9 +433,18 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
     if y_geom is None:
         if out is None:
             out = Act.empty(x.B, Ho, Wo, Cout, odt, dev, needs_grad, tag)
-        assert out.t.dtype == odt and (out.B, out.H, out.W) == (x.B, Ho, Wo), "conv output geometry mismatch"
+        if _cls is None:
+            assert out.t.dtype == odt and (out.B, out.H, out.W) == (x.B, Ho, Wo), "conv output geometry mismatch"
+            p.y_sB, p.y_sP = Ho * Wo * out.Cs, out.Cs
+        else:       # parity class (a, c) of a stride-2 input gradient (mpn.h: y_step): output pixel (i, j) -> (2 i + a, 2 j + c) of `out`
+            ca, cc_, p.y_H, p.y_W = _cls[0], _cls[1], out.H, out.W
+            p.y_step, p.y_oh, p.y_ow = 2, ca, cc_
+            if len(_cls) > 4 and _cls[4] == 1:          # 1x1 filter: its only tap
+                p.w_taps, p.wtap0, p.wtap_dr, p.wtap_ds = 1, 0, 0, 0
+            else:                                       # 3x3, pad 1: tap (t_r, t_s) of the class is filter tap (a + 1 - 2 t_r, c + 1 - 2 t_s)
+                p.w_taps, p.wtap0, p.wtap_dr, p.wtap_ds = 9, (ca + 1) * 3 + (cc_ + 1), -6, -2
+            p.y_sB, p.y_sP = out.H * out.W * out.Cs, out.Cs
         p.y = out.t.data_ptr()
-        p.y_sB, p.y_sP = Ho * Wo * out.Cs, out.Cs
         p.Cout_store = out.Cs if cout_store is None else cout_store
     else:
         yt, ysB, ysP = y_geom
@@ -480,8 +500,13 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         by, bz, st, relu = bnb[:4]
         assert y_geom is None and not out_f32 and by.t.shape == out.t.shape and by.t.dtype == out.t.dtype
         tiles = call("mpn_conv_stats_tiles", ctypes.byref(p))
-        stats = torch.empty((tiles, Cout, 2), dtype=torch.float32, device=dev)
-        p.bnb_partial = stats.data_ptr()
+        if _cls is None:
+            stats = torch.empty((tiles, Cout, 2), dtype=torch.float32, device=dev)
+            p.bnb_partial = stats.data_ptr()
+        else:       # rows [tile0, tile0 + tiles) of the table the four class launches share
+            stats, tile0 = _cls[2], _cls[3]
+            assert tile0 + tiles <= stats.shape[0]
+            p.bnb_partial = stats.data_ptr() + tile0 * Cout * 2 * 4
         p.bnb_y = by.t.data_ptr()
         p.bnb_z = bz.t.data_ptr() if bz is not None else None
         if bz is not None and bz.mask is not None:          # the ReLU mask as bits (bn_act(want_mask=True)): z itself is not read
@@ -489,7 +514,7 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         p.bnb_mean, p.bnb_invstd = st.mean.data_ptr(), st.invstd.data_ptr()
         p.bnb_scale, p.bnb_shift = st.scale.data_ptr(), st.shift.data_ptr()
         p.bnb_relu = 1 if relu else 0
-        if len(bnb) > 4 and bnb[4] is not None and fin_in_launch(tiles):
+        if _cls is None and len(bnb) > 4 and bnb[4] is not None and fin_in_launch(tiles):
             # ... and the last workgroup of every channel tile finishes the reduction: dgamma / dbeta and the (k1, k2, k3) of
             # dy = k1*g + k2*y + k3 (mpn_bn_bwd_finalize's work); the coefficient tensor comes back in the stats slot
             gamma, train, dgamma, dbeta = bnb[4]
@@ -526,6 +551,30 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
     else:
         call("mpn_conv_forward", ctypes.byref(p), stream_ptr())
     return out, stats
+
+
+DGRAD_S2_CLASSES = os.environ.get("MPN_DGRAD_S2_CLASSES", "1") != "0"
+
+
+def _conv_dgrad_s2_classes(dy, wt, Cout, out_hw, cin, out, accumulate, bnb, needs_grad, tag):
+    """Input gradient of a 3x3 / stride 2 / pad 1 convolution as four parity-class launches (mpn.h: y_step): the pixel (h, w) of dx only
+    receives the taps with r = (h + 1) mod 2 (+ 2), s likewise — 1, 2, 2 or 4 of the nine — so each class is a small stride-1 gather over
+    dy written to every second row / column of dx; together 2.25 taps per pixel instead of the 9 (6.75 of them against zeros) of the
+    strided gather.  The BatchNorm-backward statistics of the epilogue (bnb) fill consecutive row ranges of ONE partial table."""
+    H, W = out_hw
+    dev, dt = dy.t.device, dy.t.dtype
+    if out is None:
+        out = Act.empty(dy.B, H, W, Cout, dt, dev, needs_grad, tag)
+    grids = [(a, c, (H - a + 1) // 2, (W - c + 1) // 2) for a in (0, 1) for c in (0, 1)]
+    tiles = [(dy.B * ho * wo + 127) // 128 for _, _, ho, wo in grids]
+    part = torch.empty((sum(tiles), Cout, 2), dtype=torch.float32, device=dev) if bnb is not None else None
+    tile0 = 0
+    for (a, c, ho, wo), t in zip(grids, tiles):
+        if t > 0:
+            conv_forward(dy, wt, Cout, 1 + a, 1 + c, 1, 0, out=out, accumulate=accumulate, mode=0, out_hw=(ho, wo), cin=cin, bnb=bnb,
+                         _cls=(a, c, part, tile0))
+        tile0 += t
+    return out, part
 
 
 def conv_wgrad(x, dy, dw, Cout, R, S, stride, pad, cin=None, x_geom=None, db=None):

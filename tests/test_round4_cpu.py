@@ -107,6 +107,9 @@ def _hot_kernels():
     # conv2 through the virtual concatenation (extended epilogue, one launch per pass): 6 VGPRs / 27 SGPRs spilled in its prologue
     # and epilogue, none in the k-loop (checked in the ISA listing) — tolerated up to 8
     hot.append((mangled("conv_igemm_s3_kernel", "t", 256, 128, False, True, True, False), 2, 73728, 8))
+    # the parity-class launches of the stride-2 input gradients (round 4: seven per step) take conv_igemm_kernel's extended instantiation
+    hot.append((mangled("conv_igemm_kernel", "t", 128, 128, False, True, True, False), 3, 49152))
+    hot.append((mangled("conv_igemm_kernel", "t", 256, 128, False, True, True, False), 2, 73728))
     for tm, tn, lds in ((128, 128, 49152), (128, 64, 36864), (64, 128, 36864), (64, 64, 24576)):
         hot.append((mangled("conv_wgrad_dma_kernel", tm, tn), 3, lds))
         hot.append((mangled("conv_wgrad_dma_lin_kernel", tm, tn), 3, lds))      # the instantiation nearly every launch of the step takes (round 4)

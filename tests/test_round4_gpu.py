@@ -517,3 +517,120 @@ def test_wgrad_instantiations_match_torch(case):
     dw3 = torch.zeros_like(dw)
     ops.conv_wgrad(to_act(x, dtype), to_act(dy, dtype), dw3, Cout, k, k, stride, pad)
     assert torch.equal(dw2, dw3), "weight gradient differs from run to run"
+
+
+# ------------------------------------------------------------------------------------------------ parity classes of the stride-2 input gradient
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 64), (2, 15, 15, 64, 128), (1, 30, 28, 128, 96), (3, 9, 7, 32, 64), (1, 120, 120, 128, 128)])
+def test_stride2_input_gradient_by_parity_classes_matches_torch_and_the_gather(dtype, case):
+    """torch.nn.Conv2d(3, stride=2, padding=1) backward w.r.t. its input (network/layers.py: first Bottleneck of layer2-4; posenet.py P6 / P7).
+    The strided gather multiplies 6.75 of 9 taps with zeros; four parity-class launches (mpn.h: y_step, w_taps) compute only the live taps
+    and write every second row / column of dx.  Against torch autograd (the reference) and against the gather form of the same library, with and
+    without accumulation into an existing dx; odd extents (the last class row / column does not exist), extents smaller than a tile."""
+    import math
+    from multiposenet.pytorch_amd import ops
+    B, H, W, Cin, Cout = case
+    x = rnd(dtype, rng_normal(61, B, Cin, H, W)).requires_grad_(True)
+    w = rnd(dtype, rng_normal(62, Cout, Cin, 3, 3) / math.sqrt(Cin * 9.0))
+    y = F.conv2d(x, w, None, stride=2, padding=1)
+    dy = rnd(dtype, rng_normal(63, *y.shape))
+    y.backward(dy)
+    kc = 32
+    cout_pad = (Cout + kc - 1) // kc * kc
+    wm = w.permute(0, 2, 3, 1).contiguous().cuda()
+    wt = torch.empty((Cin, 3, 3, cout_pad), dtype=dtype, device="cuda")
+    ops.weight_transpose(wm, wt, Cout, 9, Cin, cout_pad)
+    dya = to_act(dy, dtype)
+    base = rnd(dtype, rng_normal(64, B, Cin, H, W))
+    res = {}
+    names = {}
+    for classes in (False, True):
+        ops.DGRAD_S2_CLASSES = classes
+        try:
+            ops.KERNEL_EVENTS.enable()
+            dx, _ = ops.conv_forward(dya, wt, Cin, 3, 3, 2, 1, mode=1, out_hw=(H, W), cin=cout_pad)
+            names[classes] = [r[0] for r in ops.KERNEL_EVENTS.rec]
+            ops.KERNEL_EVENTS.disable()
+            acc = to_act(base, dtype)
+            ops.conv_forward(dya, wt, Cin, 3, 3, 2, 1, mode=1, out_hw=(H, W), cin=cout_pad, out=acc, accumulate=True)
+        finally:
+            ops.KERNEL_EVENTS.disable()
+            ops.DGRAD_S2_CLASSES = True
+        res[classes] = (from_act(dx), from_act(acc))
+    assert len(names[False]) == 1 and len(names[True]) == sum(1 for a in (0, 1) for c in (0, 1) if (H - a + 1) // 2 > 0 and (W - c + 1) // 2 > 0), names
+    check_close("dgrad s2 classes %s %s" % (case, dtype), res[True][0], x.grad, dtype)
+    check_close("dgrad s2 classes + accumulate %s %s" % (case, dtype), res[True][1], x.grad + base, dtype)
+    d = float((res[True][0] - res[False][0]).norm() / res[False][0].norm())
+    report("stride-2 dgrad %s %s: parity classes vs gather rel-L2 %.2e (summation order of the live taps differs)" % (case, dtype, d))
+    assert d <= 3e-3
+
+
+@pytest.mark.parametrize("mode", ["train", "frozen_affine"])
+def test_training_step_with_parity_class_dgrads_equals_the_gather_step(mode):
+    """Same R101 training step with the stride-2 input gradients computed by parity classes and by the strided gather: identical loss
+    (the forward pass is untouched), gradient arena equal up to bf16 rounding of differently ordered sums; the BatchNorm-backward statistics
+    that ride in those launches' epilogues (four row ranges of one partial table) included."""
+    from multiposenet.pytorch_amd import ops
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    from test_round2_gpu import _train_setup
+    m, inputs, gts = _train_setup(101, torch.bfloat16, 2, 160, seed=170)
+    if mode == "frozen_affine":
+        m.freeze_bn()
+    bn0 = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
+    res = []
+    try:
+        for classes in (False, True):
+            ops.DGRAD_S2_CLASSES = classes
+            m.load_state_dict(bn0, strict=False)
+            m._arena.ensure_grads()
+            m._arena.grad_flat.zero_()
+            pred, saved = m(*inputs)
+            loss, log = poseNet.build_loss(saved, *gts)
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((loss.detach().clone(), m._arena.grad_flat.clone()))
+    finally:
+        ops.DGRAD_S2_CLASSES = True
+        m.train()
+    (l0, g0), (l1, g1) = res
+    assert torch.equal(l0, l1)
+    rel = float((g0 - g1).norm() / g0.norm())
+    report("training step, stride-2 dgrads by parity classes vs gather (%s): gradient arena rel-L2 %.2e" % (mode, rel))
+    assert rel <= 1e-2
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 128), (2, 15, 13, 128, 256), (1, 60, 60, 256, 512)])
+def test_stride2_1x1_input_gradient_touches_only_the_even_pixels(case):
+    """The ResNet down-sampling shortcut (network/fpn.py:37: 1x1, stride 2) backward w.r.t. its input, accumulated into an existing dx: only
+    dx[:, :, ::2, ::2] changes.  One parity-class launch over a quarter of the pixels against the strided gather over all of them and against
+    torch autograd."""
+    import math
+    from multiposenet.pytorch_amd import ops
+    B, H, W, Cin, Cout = case
+    dtype = torch.bfloat16
+    x = rnd(dtype, rng_normal(71, B, Cin, H, W)).requires_grad_(True)
+    w = rnd(dtype, rng_normal(72, Cout, Cin, 1, 1) / math.sqrt(Cin))
+    y = F.conv2d(x, w, None, stride=2)
+    dy = rnd(dtype, rng_normal(73, *y.shape))
+    y.backward(dy)
+    wm = w.permute(0, 2, 3, 1).contiguous().cuda()
+    wt = torch.empty((Cin, 1, 1, Cout), dtype=dtype, device="cuda")
+    ops.weight_transpose(wm, wt, Cout, 1, Cin, Cout)
+    base = rnd(dtype, rng_normal(74, B, Cin, H, W))
+    res = {}
+    for classes in (False, True):
+        ops.DGRAD_S2_CLASSES = classes
+        try:
+            acc = to_act(base, dtype)
+            ops.KERNEL_EVENTS.enable()
+            ops.conv_forward(to_act(dy, dtype), wt, Cin, 1, 1, 2, 0, mode=1, out_hw=(H, W), cin=Cout, out=acc, accumulate=True)
+            names = [r[0] for r in ops.KERNEL_EVENTS.rec]
+        finally:
+            ops.KERNEL_EVENTS.disable()
+            ops.DGRAD_S2_CLASSES = True
+        res[classes] = from_act(acc)
+        assert len(names) == 1
+    check_close("1x1 s2 dgrad class %s" % (case,), res[True], x.grad + base, dtype)
+    assert torch.equal(res[True], res[False]), "one tap per pixel: the class launch and the gather must agree bit for bit"
+    odd = res[True].clone(); odd[:, :, ::2, ::2] = base[:, :, ::2, ::2]
+    assert torch.equal(odd, base), "pixels outside the even grid changed"
