@@ -544,7 +544,8 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
             byts = x.B * H * W * Cin * es + x.B * Ho * Wo * p.Cout_store * (4 if out_f32 else es) * (2 if accumulate else 1) \
                 + (x.B * Ho * Wo * p.Cout_store * es if res is not None and res_mode == 1 else 0)
             name = "%s %dx%d %d->%d @%dx%d s%d%s%s%s%s%s|%d" % (
-                "dgrad" if mode == 1 else "fwd", R, S, Cin, Cout, Ho, Wo, stride, " stats" if want_stats else "",
+                ("dgrad s2 class(%d,%d)" % (_cls[0], _cls[1])) if _cls is not None else ("dgrad" if mode == 1 else "fwd"), R, S, Cin, Cout, Ho, Wo, stride,
+                " stats" if want_stats else "",
                 " bias" if bias is not None else "", " act%d" % act if act else "", " res%d" % res_mode if res is not None else "",
                 " acc" if accumulate else "", byts)
         KERNEL_EVENTS.end(name, flops, e0)

@@ -509,7 +509,9 @@ def test_bn_finalize_inside_the_conv_launch(dtype, mode, size):
     rs = max(float((r0[k].float() - r1[k].float()).abs().max() / r0[k].float().abs().max().clamp_min(1e-12)) for k in r0)
     report("BN finalize inside the conv launch (%s, %s, %dx%d): %d -> %d finalize launches; loss rel %.1e, gradient arena rel-L2 %.2e, "
            "running statistics max rel %.1e" % (str(dtype), mode, size, size, calls[0], calls[1], rel_l, rel, rs))
-    assert calls[0] >= len(m._bns) and (calls[1] <= 8 if size <= 160 else calls[1] < calls[0])
+    # (<= 11 of 208 stay separate at 160x160: three of them since round 4 — the stride-2 input gradients run as four parity-class launches,
+    #  whose shared partial table is reduced by a finalize launch)
+    assert calls[0] >= len(m._bns) and (calls[1] <= 11 if size <= 160 else calls[1] < calls[0])
     assert rel_l <= (1e-6 if dtype == torch.float32 else 1e-3) and rs <= 1e-5
     assert rel <= (2e-5 if dtype == torch.float32 else 1e-2)
 
