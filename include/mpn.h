@@ -131,7 +131,7 @@ typedef struct MpnConvParams {
      * (y_step i + y_oh, y_step j + y_ow) of the dense [B][y_H][y_W] tensor y (and of every output-shaped operand: accumulate, bnb_y,
      * bnb_mask), and whose filter tap (t_r, t_s) is tap wtap0 + t_r wtap_dr + t_s wtap_ds of a weight tensor with w_taps taps per output
      * channel ([Cout][w_taps][Cin]).  Ho, Wo = the class grid (ceil((y_H - a) / 2), ceil((y_W - c) / 2)); rows of dy past its end read zeros.
-     * 16-bit operands, extended epilogue; not combined with nseg, kseg_n, res, fin_counters, stats.  (torch.nn.Conv2d(stride=2) backward:
+     * Extended epilogue; not combined with nseg, kseg_n, res, fin_counters, stats, out_f32.  (torch.nn.Conv2d(stride=2) backward:
      * network/layers.py, the first Bottleneck of layer2-4; posenet.py P6 / P7.)                                                        */
     int32_t y_step, y_oh, y_ow, y_H, y_W;
     int32_t w_taps, wtap0, wtap_dr, wtap_ds;

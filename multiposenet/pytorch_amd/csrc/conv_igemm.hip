@@ -1149,7 +1149,7 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
                                      (!p.bnb_relu || p.bnb_z || p.bnb_mask || (p.bnb_scale && p.bnb_shift)) &&
                                      (!p.bnb_mask || ((p.y_step > 1 || p.y_sB == (int64_t)p.Ho * p.Wo * p.y_sP) && p.y_sP == p.Cout_store))));
     if (p.y_step != 0 || p.w_taps != 0) {      // parity-class launch of a strided input gradient (mpn.h)
-        MPN_CHECK_ARG(p.y_step == 2 && p.w_taps > 0 && p.dtype != MPN_F32 && !p.out_f32 && p.mode == 0 && p.stride == 1 && p.pad == 0 && !p.nseg && !p.kseg_n);
+        MPN_CHECK_ARG(p.y_step == 2 && p.w_taps > 0 && !p.out_f32 && p.mode == 0 && p.stride == 1 && p.pad == 0 && !p.nseg && !p.kseg_n);
         MPN_CHECK_ARG(!p.res_mode && !p.fin_counters && !p.stats && !p.bias && !p.scale && !p.act);
         MPN_CHECK_ARG(p.y_oh >= 0 && p.y_oh < 2 && p.y_ow >= 0 && p.y_ow < 2 && p.R >= 1 && p.R <= 2 && p.S >= 1 && p.S <= 2);
         MPN_CHECK_ARG(p.y_H > 0 && p.y_W > 0 && 2 * (p.Ho - 1) + p.y_oh < p.y_H && 2 * (p.Wo - 1) + p.y_ow < p.y_W);

@@ -407,7 +407,7 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
     """
     dev = x.t.device
     dt = x.t.dtype
-    if (DGRAD_S2_CLASSES and _cls is None and mode == 1 and stride == 2 and is16(dt) and not out_f32
+    if (DGRAD_S2_CLASSES and _cls is None and mode == 1 and stride == 2 and not out_f32
             and res is None and not want_stats and bias is None and scale is None and act == 0 and x_geom is None and y_geom is None
             and out_hw is not None):
         if R == 3 and S == 3 and pad == 1:

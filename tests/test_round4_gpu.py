@@ -520,7 +520,7 @@ def test_wgrad_instantiations_match_torch(case):
 
 
 # ------------------------------------------------------------------------------------------------ parity classes of the stride-2 input gradient
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64), (2, 15, 15, 64, 128), (1, 30, 28, 128, 96), (3, 9, 7, 32, 64), (1, 120, 120, 128, 128)])
 def test_stride2_input_gradient_by_parity_classes_matches_torch_and_the_gather(dtype, case):
     """torch.nn.Conv2d(3, stride=2, padding=1) backward w.r.t. its input (network/layers.py: first Bottleneck of layer2-4; posenet.py P6 / P7).
@@ -535,7 +535,7 @@ def test_stride2_input_gradient_by_parity_classes_matches_torch_and_the_gather(d
     y = F.conv2d(x, w, None, stride=2, padding=1)
     dy = rnd(dtype, rng_normal(63, *y.shape))
     y.backward(dy)
-    kc = 32
+    kc = 16 if dtype == torch.float32 else 32
     cout_pad = (Cout + kc - 1) // kc * kc
     wm = w.permute(0, 2, 3, 1).contiguous().cuda()
     wt = torch.empty((Cin, 3, 3, cout_pad), dtype=dtype, device="cuda")
@@ -562,7 +562,7 @@ def test_stride2_input_gradient_by_parity_classes_matches_torch_and_the_gather(d
     check_close("dgrad s2 classes + accumulate %s %s" % (case, dtype), res[True][1], x.grad + base, dtype)
     d = float((res[True][0] - res[False][0]).norm() / res[False][0].norm())
     report("stride-2 dgrad %s %s: parity classes vs gather rel-L2 %.2e (summation order of the live taps differs)" % (case, dtype, d))
-    assert d <= 3e-3
+    assert d <= (2e-6 if dtype == torch.float32 else 3e-3)
 
 
 @pytest.mark.parametrize("mode", ["train", "frozen_affine"])
