@@ -566,16 +566,28 @@ def _conv_dgrad_s2_classes(dy, wt, Cout, out_hw, cin, out, accumulate, bnb, need
     dev, dt = dy.t.device, dy.t.dtype
     if out is None:
         out = Act.empty(dy.B, H, W, Cout, dt, dev, needs_grad, tag)
-    grids = [(a, c, (H - a + 1) // 2, (W - c + 1) // 2) for a in (0, 1) for c in (0, 1)]
-    tiles = [(dy.B * ho * wo + 127) // 128 for _, _, ho, wo in grids]
-    part = torch.empty((sum(tiles), Cout, 2), dtype=torch.float32, device=dev) if bnb is not None else None
-    tile0 = 0
-    for (a, c, ho, wo), t in zip(grids, tiles):
+    plan = dgrad_s2_class_plan(dy.B, H, W)
+    rows = sum(t for _, _, _, _, t, _ in plan)
+    part = torch.empty((rows, Cout, 2), dtype=torch.float32, device=dev) if bnb is not None else None
+    for a, c, ho, wo, t, tile0 in plan:
         if t > 0:
             conv_forward(dy, wt, Cout, 1 + a, 1 + c, 1, 0, out=out, accumulate=accumulate, mode=0, out_hw=(ho, wo), cin=cin, bnb=bnb,
                          _cls=(a, c, part, tile0))
-        tile0 += t
     return out, part
+
+
+def dgrad_s2_class_plan(B, H, W, tile_pixels=128):
+    """The four parity classes of a 3x3 / stride 2 / pad 1 input gradient over a [B][H][W] dx: (a, c, class rows, class columns, pixel tiles,
+    first row of the class in the shared statistics table).  Class (a, c) owns the pixels (2 i + a, 2 j + c); its launch has (1 + a) x (1 + c)
+    taps, tap (t_r, t_s) being filter tap (a + 1 - 2 t_r, c + 1 - 2 t_s) applied to dy[i + t_r][j + t_s]."""
+    plan, tile0 = [], 0
+    for a in (0, 1):
+        for c in (0, 1):
+            ho, wo = (H - a + 1) // 2, (W - c + 1) // 2
+            t = (B * ho * wo + tile_pixels - 1) // tile_pixels
+            plan.append((a, c, ho, wo, t, tile0))
+            tile0 += t
+    return plan
 
 
 def conv_wgrad(x, dy, dw, Cout, R, S, stride, pad, cin=None, x_geom=None, db=None):

@@ -149,3 +149,40 @@ def test_hot_kernels_have_no_scratch_and_keep_their_occupancy_class():
     # nothing in the library may use a stack (dynamic or fixed scratch beyond spills would mean recursion / big local arrays)
     stacky = [k["name"] for k in ks if k["scratch"] > 1024]
     assert not stacky, "kernels with > 1 KB of scratch per lane: %s" % stacky
+
+
+def test_stride2_dgrad_class_plan_covers_every_pixel_and_every_live_tap_once():
+    """ops.dgrad_s2_class_plan (host logic of the parity-class input gradient, mpn.h: y_step).  Against a brute-force statement of
+    torch.nn.Conv2d(3, stride=2, padding=1) backward: dx[h][w] += dy[i][j] * W[r][s] for every (i, j, r, s) with 2 i - 1 + r = h and 2 j - 1 + s = w.
+    The classes must tile dx exactly once, their taps must be exactly the live (dy pixel, filter tap) pairs of each pixel, and the table rows
+    must be consecutive — for even, odd and degenerate extents."""
+    from multiposenet.pytorch_amd.ops import dgrad_s2_class_plan
+    for (B, H, W) in [(2, 16, 16), (1, 15, 15), (3, 9, 7), (1, 1, 1), (2, 1, 8), (1, 120, 30)]:
+        Hd, Wd = (H - 1) // 2 + 1, (W - 1) // 2 + 1                      # dy extent of a stride-2 / pad-1 / 3x3 convolution
+        want = {}
+        for i in range(Hd):
+            for j in range(Wd):
+                for r in range(3):
+                    for s in range(3):
+                        h, w = 2 * i - 1 + r, 2 * j - 1 + s
+                        if 0 <= h < H and 0 <= w < W:
+                            want.setdefault((h, w), set()).add((i, j, r, s))
+        got, next_row = {}, 0
+        for a, c, ho, wo, tiles, tile0 in dgrad_s2_class_plan(B, H, W):
+            assert tile0 == next_row and tiles == (B * ho * wo + 127) // 128
+            next_row += tiles
+            for i in range(ho):
+                for j in range(wo):
+                    h, w = 2 * i + a, 2 * j + c
+                    assert h < H and w < W and (h, w) not in got, "class (%d,%d) pixel (%d,%d) out of range or owned twice" % (a, c, h, w)
+                    taps = set()
+                    for tr in range(1 + a):
+                        for ts in range(1 + c):
+                            r, s = a + 1 - 2 * tr, c + 1 - 2 * ts
+                            assert 0 <= r < 3 and 0 <= s < 3 and (a + 1) * 3 + (c + 1) - 6 * tr - 2 * ts == r * 3 + s      # wtap0 / wtap_dr / wtap_ds
+                            if i + tr < Hd and j + ts < Wd:                                                                # rows past dy read zeros
+                                taps.add((i + tr, j + ts, r, s))
+                    got[(h, w)] = taps
+        assert set(got) == {(h, w) for h in range(H) for w in range(W)}, (B, H, W)
+        for k in got:
+            assert got[k] == want.get(k, set()), (B, H, W, k)
