@@ -923,6 +923,10 @@ def gather_dets(dets, keep):
     return boxes, scores
 
 
+_NMS_PRE_TOPN_ENV = int(os.environ.get("MPN_NMS_PRE_TOPN", "0"))      # default cap of candidates per image entering NMS (0 = none, as the reference)
+_NMS_WARNED = []
+
+
 def detect_batched(boxes, scores, score_thresh, iou_thresh, mode=0, ws_limit=4 << 30, padded=False, pre_nms_top_n=None):
     """Score filter + per-image NMS + gather for EVERY image of a batch with two host round trips per batch (the candidate
     counts size the NMS launches, the kept counts size the returned tensors) instead of two per image.
@@ -942,7 +946,16 @@ def detect_batched(boxes, scores, score_thresh, iou_thresh, mode=0, ws_limit=4 <
             return torch.zeros((B, 0, 4), dtype=torch.float32, device=dev), torch.zeros((B, 0), dtype=torch.float32, device=dev), [0] * B
         return [(None, None)] * B
     ncand = nmax
+    if pre_nms_top_n is None and _NMS_PRE_TOPN_ENV > 0:
+        pre_nms_top_n = _NMS_PRE_TOPN_ENV
     top = int(pre_nms_top_n) if pre_nms_top_n else 0
+    if top == 0 and nmax > 32768 and not _NMS_WARNED:
+        # the reference's behaviour (every candidate above the score threshold enters the suppression) costs an N x N / 64 mask per image:
+        # 134 MB at 32 768 candidates, 1.2 GB at 100 000 — say so once instead of silently taking seconds
+        import warnings
+        _NMS_WARNED.append(True)
+        warnings.warn("NMS over %d candidates in one image (N x N / 64 mask = %.0f MB per image); pass pre_nms_top_n or set MPN_NMS_PRE_TOPN "
+                      "to bound it (not in the reference)" % (nmax, nmax * float(nmax) / 64 * 8 / 1e6))
     if top > 0:
         nmax = min(nmax, top)                          # rows of the sort / mask scratch and of the outputs
     keep = torch.empty((B, nmax), dtype=torch.int64, device=dev)
