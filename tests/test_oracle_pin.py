@@ -210,3 +210,28 @@ def test_peak_extraction_restatement_vs_reference(case):
     if int(g["refined"]) == 1:
         refd = np.concatenate([p.reshape(-1, 4) for p in jo.nms_peaks(0.1, heat, up, refine=True)])
         assert np.array_equal(refd, g["nms_refined_" + case])
+
+
+def test_reference_nms_kernel_builds_unmodified_into_oracle_ref():
+    """oracle/_ref: /root/reference/lib/nms/src/cuda/nms_kernel.cu compiled in place with hipcc (recipe: oracle/Makefile `ref`).
+    Here (no GPU) only: the recipe runs where the reference tree exists, both variants export `_nms`, and the files stay out of
+    history (.gitignore) but travel to the GPU box (.gpurunignore does not list them).  The comparison itself is
+    tests/test_nms_ref_gpu.py (-m gpu)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/root/reference/lib/nms/src/cuda/nms_kernel.cu"):
+        pytest.skip("reference tree not present (GPU box): the prebuilt oracle/_ref files are used as they are")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "ref"])
+    for so in ("libref_nms_kernel.so", "libref_nms_kernel_nocontract.so"):
+        p = os.path.join(root, "oracle", "_ref", so)
+        assert os.path.exists(p), p
+        syms = subprocess.check_output(["nm", "-D", "--defined-only", p]).decode()
+        assert " T _nms" in syms and "nms_kernel" in syms
+    assert "oracle/_ref/" in open(os.path.join(root, ".gitignore")).read()
+    gi = os.path.join(root, ".gpurunignore")
+    assert not os.path.exists(gi) or "oracle/_ref" not in open(gi).read()
+    # the recipe must never write into the reference tree (make's built-in `%: %.o` rule once tried to "link" nms_kernel.cu
+    # from the nms_kernel.cu.o lying next to it; built-in rules are off in oracle/Makefile)
+    mk = open(os.path.join(root, "oracle", "Makefile")).read()
+    assert ".SUFFIXES:" in mk and "MAKEFLAGS += -r" in mk
