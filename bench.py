@@ -16,8 +16,8 @@ arena overlapped with backward); weak scaling (32 images per GPU).
 error (exit status 3, no JSON line), never a silently smaller job.
 
 The timed step is the recorded step of multiposenet/pytorch_amd/replay.py (forward, losses, zero_grad, backward on two
-HIP streams, RCCL buckets, Adam — recorded once as a launch list and re-issued per step (replay.py); `--launch graph`
-times a captured hipGraph instead, `--launch eager` the Python tape).  Every timed
+HIP streams, RCCL buckets, Adam — recorded once as a launch list and re-issued per step (replay.py); `--launch eager`
+times the Python tape instead).  Every timed
 step is also bracketed by a pair of HIP events on the launch stream; their median is reported beside the wall-clock
 mean that `value` is computed from.
 
@@ -59,9 +59,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--eager-log", action="store_true", help="plain-float loss logs (one host sync per step, the reference's behaviour)")
-    ap.add_argument("--launch", default="replay", choices=["replay", "graph", "eager"],
-                    help="replay: recorded launch list (replay.py, default); graph: captured hipGraph (graph.py); eager: the Python tape")
-    ap.add_argument("--no-graph", action="store_true", help="same as --launch eager")
+    ap.add_argument("--launch", default="replay", choices=["replay", "eager"],
+                    help="replay: recorded launch list (replay.py, default); eager: the Python tape")
     ap.add_argument("--instr-steps", type=int, default=2, help="instrumented eager steps per schedule after the timed region")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-baseline-worker", action="store_true")
@@ -252,8 +251,6 @@ def main():
         dist = None
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if use_dist else 0)
-    if os.environ.get("MPN_MAIN_PRIORITY"):         # scheduling experiment: the step's main stream as a prioritised HIP stream
-        torch.cuda.set_stream(torch.cuda.Stream(dev, priority=int(os.environ["MPN_MAIN_PRIORITY"])))
 
     from multiposenet.pytorch_amd import ddp, ops
     from multiposenet.pytorch_amd.network.posenet import poseNet
@@ -267,21 +264,20 @@ def main():
     for p in model.prn.parameters():          # PRN is not part of this step (all non-PRN params trainable)
         p.requires_grad = False
     model.train()
+    reducer = None
     if use_dist:
-        ddp.attach(model, bucket_mb=32.0)
+        reducer = ddp.attach(model, bucket_mb=32.0)
+        reducer.measure = True
     opt = FusedAdam(model, lr=1e-4, weight_decay=0.0)
     img, heat, wgt, anno = synth(args.batch, args.size, dev, seed=100 + rank)
 
     last_log = {}
-    from multiposenet.pytorch_amd.graph import GraphedTrainStep
     from multiposenet.pytorch_amd.replay import ReplayedTrainStep
     from multiposenet.pytorch_amd.training.batch_processor import train_step
     inputs = [[img, args.subnet]]
     gts = {"train_both": ["train_both", heat, wgt, anno], "keypoint_subnet": ["keypoint_subnet", heat, wgt],
            "detection_subnet": ["detection_subnet", anno]}[args.subnet]
-    if args.no_graph:
-        args.launch = "eager"
-    gstep = {"replay": lambda: ReplayedTrainStep(model, opt), "graph": lambda: GraphedTrainStep(model, opt), "eager": lambda: None}[args.launch]()
+    gstep = ReplayedTrainStep(model, opt) if args.launch == "replay" else None
 
     def step():
         loss, log = gstep(inputs, gts) if gstep is not None else train_step(model, opt, inputs, gts)
@@ -309,7 +305,24 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    dist_info = None
     if dist is not None:
+        # what the line needs for a reader to see that the collective library really saw `world` ranks
+        per_rank = [None] * dist.get_world_size()
+        dist.all_gather_object(per_rank, {"rank": rank, "ms_per_step": round(elapsed / args.steps * 1000.0, 3),
+                                          "allreduce_ms_exposed": None if reducer.exposed_ms() is None else round(reducer.exposed_ms(), 3)})
+        backend = dist.get_backend()
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:           # noqa: BLE001 — a build without the binding: say so instead of failing the bench
+            rccl = "unavailable"
+        dist_info = {"backend": backend, "world_size": dist.get_world_size(), "rccl_version": rccl,
+                     "buckets": len(reducer.buckets), "bucket_mb": reducer.bucket_mb, "collectives_per_step": reducer.launched,
+                     "gradient_bytes_per_step": int(sum(b["end"] - b["start"] for b in reducer.buckets) * 4),
+                     "per_rank_ms": [r["ms_per_step"] for r in sorted(per_rank, key=lambda r: r["rank"])],
+                     "allreduce_ms_exposed": [r["allreduce_ms_exposed"] for r in sorted(per_rank, key=lambda r: r["rank"])],
+                     "allreduce_ms_exposed_how": "HIP events on the launch stream around the waits of GradReducer.finish() in the last timed "
+                                                 "step: GPU time between the end of backward and the last collective's completion"}
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.shared_device_test else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -373,10 +386,11 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "loss_log": "eager floats (host sync per step)" if args.eager_log else "asynchronous (set_lazy_log)",
                        "launch": {"eager": "eager Python tape (autograd node + ~2300 ctypes launches built per step)",
-                                  "graph": "one hipGraph replay per step",
                                   "replay": "recorded launch list re-issued per step (replay.py)"}[args.launch]
                                  + ("" if gstep is None else ", %d replays" % gstep.replays)},
         }
+        if dist_info is not None:
+            out["dist"] = dist_info
         if args.shared_device_test:
             out["not_a_measurement"] = True
             out["config"]["parallelism"] += " (TEST: %d ranks sharing one device over gloo — exercises the launch path, measures nothing)" % world

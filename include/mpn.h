@@ -114,15 +114,6 @@ typedef struct MpnConvParams {
     double fin_count;
     float fin_momentum, fin_eps;
     int32_t fin_train;
-    /* Atomic batch statistics (stats_atomic = 1, round 4): `stats` is NOT the per-tile partial table but ONE pair of 64-bit
-     * fixed-point accumulators per channel, uint64 [Cout][2], zeroed by the caller before the launch; every workgroup adds its
-     * tile's (sum, sum^2) with integer atomics: sum in units of 2^-MPN_STAT_SUM_FRAC_BITS, sum^2 in units of
-     * 2^-MPN_STAT_SQ_FRAC_BITS, each partial rounded to nearest.  Integer addition is associative, so the totals do not depend on the
-     * arrival order (deterministic), nobody waits for a last arriver and no finalize launch follows: mpn_bn_act_acc_forward turns the
-     * totals into the BatchNorm coefficients in its own prologue (network/fpn.py:28-34 in training mode).  Not combined with
-     * fin_counters.  Range: |sum| < 2^(63-28) = 3.4e10, sum^2 < 2^(63-20) = 8.8e12 (an rms of 2 000 over 2 M pixels); resolution
-     * per tile 3.7e-9 / 9.5e-7, i.e. at most 7.5e-9 on E[x^2] — three orders below the eps = 1e-5 that the variance is added to. */
-    int32_t stats_atomic;
     /* Parity classes of a stride-2 input gradient (y_step == 2; round 4).  dx[h][w] of a 3x3 / stride 2 / pad 1 convolution only receives
      * the taps r = (h + 1) mod 2 (+ 2), s likewise: of the nine taps 1, 2, 2 or 4 are live, depending on the parities (a, c) of (h, w) — the
      * gather form (mode 1, stride 2) multiplies the other 6.75 of 9 with zeros.  One launch per class computes
@@ -136,8 +127,6 @@ typedef struct MpnConvParams {
     int32_t y_step, y_oh, y_ow, y_H, y_W;
     int32_t w_taps, wtap0, wtap_dr, wtap_ds;
 } MpnConvParams;
-#define MPN_STAT_SUM_FRAC_BITS 28
-#define MPN_STAT_SQ_FRAC_BITS 20
 #define MPN_MAX_SEG 5
 
 /* number of pixel tiles (rows of `stats`) mpn_conv_forward will use for this problem */
@@ -242,15 +231,6 @@ int mpn_bn_finalize_eval(int C, const float* gamma, const float* beta, const flo
  * what the backward of relu(bn(.) + shortcut) (network/fpn.py:30-33) needs of z, at 1/16 of its bytes. */
 int mpn_bn_act_forward(const void* y, const void* res, void* z, const float* scale, const float* shift,
                        int64_t P, int C, int Cs, int relu, int dtype, uint8_t* mask, void* stream);
-/* Training forward from ATOMIC statistics (MpnConvParams.stats_atomic): acc = uint64 [C][2] fixed-point totals of (sum, sum^2) over
- * the P pixels, complete when this launch starts.  Every workgroup derives the coefficients of ITS channels in its prologue (one
- * channel per thread, shared through LDS: mean = sum / P, biased variance, invstd = 1 / sqrt(var + eps) in double precision as
- * mpn_bn_finalize_train does) and then runs mpn_bn_act_forward's stream; the first row of workgroups also writes mean / invstd /
- * scale / shift ([C] each, for the backward pass) and updates the running statistics (momentum; unbiased variance).  Replaces the
- * pair mpn_bn_finalize_train + mpn_bn_act_forward: one kernel boundary less in the chain conv -> statistics -> normalise -> conv. */
-int mpn_bn_act_acc_forward(const void* y, const void* res, void* z, int64_t P, int C, int Cs, int relu, int dtype, uint8_t* mask,
-                           const uint64_t* acc, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                           float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, void* stream);
 /* backward, stage 1: g = dz * (z > 0 if relu); partial sums of g and g*xhat per channel.
  * With relu and z == NULL the mask is recomputed as (y*mask_scale + mask_shift) > 0 — the forward's own expression
  * (valid when the forward had no residual input), which saves reading z. */

@@ -43,7 +43,6 @@ class ConvParams(ctypes.Structure):
         ("fin_counters", ctypes.c_void_p), ("fin_gamma", ctypes.c_void_p), ("fin_beta", ctypes.c_void_p), ("fin_rm", ctypes.c_void_p),
         ("fin_rv", ctypes.c_void_p), ("fin_out", ctypes.c_void_p), ("fin_dgamma", ctypes.c_void_p), ("fin_dbeta", ctypes.c_void_p),
         ("fin_count", ctypes.c_double), ("fin_momentum", ctypes.c_float), ("fin_eps", ctypes.c_float), ("fin_train", ctypes.c_int32),
-        ("stats_atomic", ctypes.c_int32),
         ("y_step", ctypes.c_int32), ("y_oh", ctypes.c_int32), ("y_ow", ctypes.c_int32), ("y_H", ctypes.c_int32), ("y_W", ctypes.c_int32),
         ("w_taps", ctypes.c_int32), ("wtap0", ctypes.c_int32), ("wtap_dr", ctypes.c_int32), ("wtap_ds", ctypes.c_int32),
     ]
@@ -101,7 +100,6 @@ SIGNATURES = {
     "mpn_bn_finalize_train": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "mpn_bn_finalize_eval": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "mpn_bn_act_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
-    "mpn_bn_act_acc_forward": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "mpn_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
     "mpn_bn_bwd_finalize": (_i, [_vp, _i, _i, _i64, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "mpn_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _vp, _vp]),
@@ -172,6 +170,16 @@ def build(force=False):
     subprocess.check_call(["make", "-s", "-j8", "-C", CSRC])
     if not os.path.exists(LIB_PATH):
         raise MpnError("build did not produce %s" % LIB_PATH)
+    return LIB_PATH
+
+
+def use_experiments_build():
+    """tools/ only: load libmpn_hip_experiments.so (csrc/Makefile `experiments`: PROF instantiations, MPN_DEBUG_FLAGS / MPN_WGRAD_ABLATE
+    ablations, environment overrides of tuned constants) instead of the production library.  Must be called before the first lib()."""
+    global LIB_PATH
+    assert _lib is None, "call use_experiments_build() before anything loads the library"
+    subprocess.check_call(["make", "-s", "-j8", "-C", CSRC, "experiments"])
+    LIB_PATH = os.path.join(_HERE, "libmpn_hip_experiments.so")
     return LIB_PATH
 
 

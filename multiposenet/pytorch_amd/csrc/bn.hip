@@ -163,82 +163,6 @@ __global__ void __launch_bounds__(256) bn_act_kernel(const T* __restrict__ y, co
     }
 }
 
-// bn_act from ATOMIC statistics (mpn.h: MpnConvParams.stats_atomic, mpn_bn_act_acc_forward).  The producing convolution left one pair
-// of fixed-point totals per channel; there is no finalize launch and nobody waits for anybody: every block turns the totals of ITS
-// GB * V channels into (scale, shift) — one channel per thread and round, shared through LDS — and then streams like bn_act_kernel.
-// The first row of blocks (blockIdx.x == 0) also writes the per-channel vectors the backward pass reads and the running statistics.
-// Arithmetic of finalize_train_block (double-precision mean / variance / invstd), so both paths agree to the totals' rounding.
-template <typename T>
-__global__ void __launch_bounds__(256) bn_act_acc_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ z,
-                                                         long P, int C, int Cs, int relu, int iters, unsigned char* __restrict__ mask,
-                                                         const unsigned long long* __restrict__ acc, double inv_count, double unbias,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float* __restrict__ rm, float* __restrict__ rv, float momentum, float eps,
-                                                         float* __restrict__ mean, float* __restrict__ invstd,
-                                                         float* __restrict__ scale, float* __restrict__ shift) {
-    constexpr int V = Vec16<T>::N;
-    __shared__ __attribute__((aligned(16))) float sh_sc[256 * V];
-    __shared__ __attribute__((aligned(16))) float sh_sf[256 * V];
-    const Geo<T> q(Cs);
-    const long p0 = (long)blockIdx.x * q.lanes * iters + q.pl;
-    // the first pixel's tensor loads do not depend on the coefficients: in flight under the prologue
-    Vec16<T> a, r;
-    const bool first = p0 < P;
-    if (first) { a.load(y + p0 * Cs + q.c0); if (res) r.load(res + p0 * Cs + q.c0); }
-    const int nch = q.GB * V, cbase = blockIdx.y * nch;
-    for (int cl = threadIdx.x; cl < nch; cl += 256) {
-        const int c = cbase + cl;
-        float sc = 0.f, sf = 0.f;
-        if (c < C) {
-            const ulonglong2 t = *reinterpret_cast<const ulonglong2*>(acc + (long)c * 2);
-            const double s1 = (double)(long long)t.x * (1.0 / (double)(1LL << MPN_STAT_SUM_FRAC_BITS));
-            const double s2 = (double)(long long)t.y * (1.0 / (double)(1LL << MPN_STAT_SQ_FRAC_BITS));
-            const double mu = s1 * inv_count;
-            double var = s2 * inv_count - mu * mu;
-            if (var < 0.0) var = 0.0;
-            const float is = (float)(1.0 / sqrt(var + (double)eps));
-            const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-            sc = g * is;
-            sf = b - (float)mu * sc;
-            if (blockIdx.x == 0) {
-                mean[c] = (float)mu; invstd[c] = is; scale[c] = sc; shift[c] = sf;
-                if (rm) rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mu;
-                if (rv) rv[c] = (1.f - momentum) * rv[c] + momentum * (float)(var * unbias);
-            }
-        }
-        sh_sc[cl] = sc; sh_sf[cl] = sf;
-    }
-    __syncthreads();
-    float sc[V], sf[V];
-    const int l0 = (threadIdx.x % q.GB) * V;
-#pragma unroll
-    for (int k = 0; k < V; k += 4) {
-        const float4 t0 = *reinterpret_cast<const float4*>(sh_sc + l0 + k), t1 = *reinterpret_cast<const float4*>(sh_sf + l0 + k);
-        sc[k] = t0.x; sc[k + 1] = t0.y; sc[k + 2] = t0.z; sc[k + 3] = t0.w;
-        sf[k] = t1.x; sf[k + 1] = t1.y; sf[k + 2] = t1.z; sf[k + 3] = t1.w;
-    }
-    for (int it = 0; it < iters; ++it) {
-        const long p = p0 + (long)it * q.lanes;
-        if (p >= P) break;
-        const long off = p * Cs + q.c0;
-        if (it > 0) { a.load(y + off); if (res) r.load(res + off); }
-#pragma unroll
-        for (int k = 0; k < V; ++k) {
-            float x = a.v[k] * sc[k] + sf[k];
-            if (res) x += r.v[k];
-            if (relu) x = fmaxf(x, 0.f);
-            a.v[k] = (q.c0 + k < C) ? x : 0.f;
-        }
-        a.store(z + off);
-        if (mask) {
-            unsigned bits = 0;
-#pragma unroll
-            for (int k = 0; k < V; ++k) bits |= (Elem<T>::round(a.v[k]) > 0.f ? 1u : 0u) << k;
-            mask[p * q.G + q.g] = (unsigned char)bits;
-        }
-    }
-}
-
 // stage 1 of backward: per (pixel-chunk, channel) partial sums of g and g*xhat
 template <typename T>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ z, const T* __restrict__ y,
@@ -375,7 +299,7 @@ inline bool geo_ok(int Cs, int V) { const int G = Cs / V; return Cs % V == 0 && 
 
 // pixels per block for the streaming kernels: ~8192 blocks per launch (32 per CU; measured -0.14 ms/step against 2048), <= 32 pixels per thread
 inline int pick_iters(long P, int lanes) {
-    static const long blocks = getenv("MPN_BN_BLOCKS") ? atol(getenv("MPN_BN_BLOCKS")) : 8192;   // blocks per launch (swept 1k..32k at step level)
+    static const long blocks = mpn_tune("MPN_BN_BLOCKS", 8192);   // blocks per launch (swept 1k..32k at step level)
     long it = P / ((long)lanes * blocks);
     if (it < 1) it = 1;
     if (it > 32) it = 32;
@@ -418,26 +342,6 @@ extern "C" int mpn_bn_act_forward(const void* y, const void* res, void* z, const
     dim3 grid((unsigned)((P + (long)lanes * iters - 1) / ((long)lanes * iters)), (unsigned)geo_yblocks(Cs, V));
     MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)y, (const T*)res,
                            (T*)z, scale, shift, (long)P, C, Cs, relu, iters, (unsigned char*)mask));
-    return mpn_launch_status();
-}
-
-extern "C" int mpn_bn_act_acc_forward(const void* y, const void* res, void* z, int64_t P, int C, int Cs, int relu, int dtype, uint8_t* mask,
-                                      const uint64_t* acc, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                      float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, void* stream) {
-    MPN_CHECK_ARG(y && z && acc && mean && invstd && scale && shift && P > 0 && C > 0 && Cs >= C && (!mask || relu));
-    const int V = dtype == MPN_F32 ? 4 : 8;
-    MPN_CHECK_ARG(mpn_dtype_ok(dtype) && geo_ok(Cs, V) && C % 4 == 0);
-    // every block pays the prologue (a dependent load -> double-precision arithmetic -> LDS -> barrier chain): ~2048 blocks, one
-    // resident round, instead of the plain kernel's 8192 (-0.25 ms/step; 1024 and 4096 measure the same within 0.05)
-    static const long blocks = getenv("MPN_BN_ACC_BLOCKS") ? atol(getenv("MPN_BN_ACC_BLOCKS")) : 2048;
-    const int lanes = geo_lanes(Cs, V);
-    int iters = pick_iters(P, lanes);
-    if (blocks > 0) { long it = P / ((long)lanes * blocks); iters = (int)(it < 1 ? 1 : (it > 32 ? 32 : it)); }
-    dim3 grid((unsigned)((P + (long)lanes * iters - 1) / ((long)lanes * iters)), (unsigned)geo_yblocks(Cs, V));
-    const double unbias = P > 1 ? (double)P / (double)(P - 1) : 1.0;
-    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_acc_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)y, (const T*)res,
-                           (T*)z, (long)P, C, Cs, relu, iters, (unsigned char*)mask, (const unsigned long long*)acc, 1.0 / (double)P, unbias,
-                           gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift));
     return mpn_launch_status();
 }
 

@@ -102,6 +102,21 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return base + local;
 }
 
+// Experiments build (`make experiments` -> libmpn_hip_experiments.so, compiled with -DMPN_EXPERIMENTS; tools/ load it explicitly):
+// the s_memtime PROF instantiations of the hot kernels, the timing-only ablation bits (MPN_DEBUG_FLAGS, MPN_WGRAD_ABLATE) and the
+// environment overrides of tuned constants.  The production library (`make`, what the package loads) compiles none of them:
+// every mpn_tune() is its default, every MPN_DBG() is false.
+#ifdef MPN_EXPERIMENTS
+#include <stdlib.h>
+#define MPN_EXP 1
+static inline long mpn_tune(const char* name, long dflt) { const char* v = getenv(name); return v ? atol(v) : dflt; }
+#define MPN_DBG(bit) ((dbg & (bit)) != 0)
+#else
+#define MPN_EXP 0
+static inline long mpn_tune(const char*, long dflt) { return dflt; }
+#define MPN_DBG(bit) false
+#endif
+
 static inline int mpn_launch_status() {
     hipError_t e = hipGetLastError();
     return (int)e;

@@ -140,22 +140,6 @@ __device__ __forceinline__ void store_partial(float* dst, float a, float b, bool
     }
 }
 
-// Atomic batch statistics (mpn.h: stats_atomic): the tile's (sum, sum^2) of one channel go into that channel's two 64-bit fixed-point
-// accumulators.  Integer atomics: the totals are the same whatever order the workgroups arrive in; no return value, so the wave does
-// not wait for them (the end of the kernel does).  One lane = one accumulator (comp 0: sum, 1: sum^2): consecutive lanes hit
-// consecutive 8-byte words, so a wave instruction covers whole lines (two atomics per lane at a 16-byte stride cost 1.8 ms/step
-// more: profiles/r04_bn_atomic_stats_ab.txt).  The XCDs' L2s are not coherent with each other, so the hardware carries every
-// global atomic out at the memory side whatever scope the source asks for (the ISA has one scope bit for atomics, device / system:
-// hipcc emits the same global_atomic_add_x2 for workgroup and agent scope) — microseconds until acknowledged, and a workgroup
-// cannot retire before that.  Hence the statistics run BEFORE the tile's stores here: the acknowledgement latency passes under the
-// store phase (-0.12 ms/step against atomics issued last).  A per-XCD copy of the accumulators (chosen by HW_REG_XCC_ID) was
-// correct and SLOWER (+0.9 ms/step: eight times the lines for the consumer to read and to zero, no cheaper atomics).
-__device__ __forceinline__ void stat_atomic_add(float* stats, int cout, int comp, float v) {
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(stats) + (long)cout * 2 + comp;
-    const long long iv = __double2ll_rn((double)v * (comp ? (double)(1LL << MPN_STAT_SQ_FRAC_BITS) : (double)(1LL << MPN_STAT_SUM_FRAC_BITS)));
-    __hip_atomic_fetch_add(acc, (unsigned long long)iv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // In-launch finalize (mpn.h: fin_*).  Every workgroup of channel tile `tc` has published its partial pair per channel; the one that
 // draws the last ticket reduces the column [ntiles][TC] in a fixed order (SL interleaved slices per channel in double precision,
 // combined in slice order) — the same numbers whichever workgroup arrives last — and writes the BatchNorm coefficients.
@@ -350,17 +334,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
             }
         __syncthreads();
         const int t = threadIdx.x;
-        if (pk.stats_atomic) {
-            for (int e = t; e < 2 * TC; e += 256) {
-                const int row = e >> 1, comp = e & 1, cout = c0 + row;
-                if (cout < p.Cout) {
-                    float v = 0.f;
-#pragma unroll
-                    for (int w = 0; w < C::WAVES_P; ++w) v += sf[(w * TC + row) * 2 + comp];
-                    stat_atomic_add(p.stats, cout, comp, v);
-                }
-            }
-        } else if (t < TC) {
+        if (t < TC) {
             const int cout = c0 + t;
             if (cout < p.Cout) {
                 float a = 0.f, q = 0.f;
@@ -373,15 +347,14 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
             }
         }
     };
-    // atomic statistics: before the stores as well (see stat_atomic_add)
-    const bool stats_first = GENERAL || pk.stats_atomic != 0;
-    if (stats_first && p.stats && !(dbg & 64)) {
+    constexpr bool stats_first = GENERAL;
+    if (stats_first && p.stats && !MPN_DBG(64)) {
         tile_stats(lds_f);
         __syncthreads();
     }
 
     // ---- phase B: stage through LDS, store whole rows ----------------------------------------------
-    if (dbg & 256) { if (acc[0][0][0] == 123.456f) ((float*)p.y)[0] = 1.f; return; }
+    if (MPN_DBG(256)) { if (acc[0][0][0] == 123.456f) ((float*)p.y)[0] = 1.f; return; }
     unsigned char* stage = lds + (threadIdx.x >> 6) * REGION;
     const int sp = lane / LPP, sc_ = lane % LPP;               // store phase: pixel slot, 16-byte chunk
     const int ccol = c0 + wc * C::WTC + sc_ * EV;              // first channel of this lane's chunk
@@ -429,7 +402,10 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
         // r04_kloop_phase_profile.txt) — so twice the loads in flight per wave: that launch 102.6 -> 96.6 us, step 37.93 -> 37.55 ms,
         // and the 128-row kernel needs FEWER registers (one group = the whole pass: 152 instead of 166 VGPRs).
         constexpr int NIT = PASS_TILES * 16 / PPI;
-        constexpr int GMAX = EXT ? 4 : 8;          // the extended epilogue carries three more load arrays per group: 8 would spill (70 VGPRs)
+        // the extended epilogue carries three more load arrays per group: 8 would spill (70 VGPRs).  (Round 5: groups of 4 for the f32-output
+        // instantiations — 8 - 10 spilled VGPRs in <float,128,128,general> / <*,128,128,OUTF32,general> — made it 78: a group that is
+        // the whole pass compiles to the simplest loop; groups of 2 for the 256-row extended tile changed nothing, its spills are in the prologue.)
+        constexpr int GMAX = EXT ? 4 : 8;
         constexpr int G = NIT < GMAX ? NIT : GMAX;
         static_assert(NIT % G == 0, "store groups");
 #pragma unroll
@@ -443,7 +419,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
             const bool add_acc = !EXT && p.res_mode == 0 && p.accumulate;      // standard kernel: accumulate rides in l_add
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                live[g] = pix < P && ccol < p.Cout_store && !(dbg & 128);
+                live[g] = pix < P && ccol < p.Cout_store && !MPN_DBG(128);
                 yo[g] = b * (unsigned)p.y_sB + rem * (unsigned)p.y_sP + (unsigned)ccol;
                 unsigned mpix = pix;                             // pixel index into the output-shaped mask tensors
                 if (YSTEP && pk.y_step > 1) {                      // parity-class launch (mpn.h): output pixel (i, j) lives at (step i + oh, step j + ow)
@@ -523,7 +499,7 @@ __device__ __forceinline__ void conv_epilogue(const MpnConvParams& p, f32x4_t (&
         }
         if (ps + 1 < NPASS) __syncthreads();
     }
-    if (!stats_first && p.stats && !(dbg & 64)) tile_stats(reinterpret_cast<float*>(lds + 4 * REGION));
+    if (!stats_first && p.stats && !MPN_DBG(64)) tile_stats(reinterpret_cast<float*>(lds + 4 * REGION));
 
     if (bnb) {
         // lanes sharing a channel chunk (same sc_, different pixel slot sp): butterfly over the sp bits
@@ -737,7 +713,7 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_kernel(const
 #pragma unroll
             for (int j = 0; j < C::MP; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
     };
-    if (dbg & 32) return;                    // ablation: prologue only
+    if (MPN_DBG(32)) return;                 // ablation: prologue only
 
     KProf kp;
     if (PROF) kp.begin();
@@ -760,7 +736,7 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_kernel(const
     const unsigned long long loop_end = PROF ? __builtin_readcyclecounter() : 0ull;
     __syncthreads();                          // the epilogue re-uses the ring as its staging area
 
-    if (dbg & 16) { if (acc[0][0][0] == 123.456f) ((float*)p.y)[0] = 1.f; return; }   // ablation: no epilogue
+    if (MPN_DBG(16)) { if (acc[0][0][0] == 123.456f) ((float*)p.y)[0] = 1.f; return; }   // ablation: no epilogue
     const int ntiles = (int)(gridDim.x / (unsigned)tilesC);       // pixel tiles of the launch (in-launch finalize)
     if (OUTF32) conv_epilogue<T, float, TC, TP, GENERAL, EXT>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
     else        conv_epilogue<T, T, TC, TP, GENERAL, EXT, EXT>(p, acc, c0, p0, wc, wp, lane, tp, lds, dbg, tc, ntiles, pk);
@@ -833,7 +809,8 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
     }
     // pixel-tile DMA units: LDS row i holds input pixel (linear index) p0 - 1 + i of the line the current kernel row selects
     unsigned b_base[LB];
-    int b_h[LB], b_w[EXT ? LB : 1], b_bi[EXT ? LB : 1];           // (column, image) only for the virtual concatenation (EXT instantiation)
+    int b_h[LB];
+    unsigned b_wb[EXT ? LB : 1];                                  // (image << 16) | column: only for the virtual concatenation (EXT instantiation; launcher: B, W < 65 536)
     bool b_ok[LB];
     const bool vcat = EXT && pk.kseg_n > 0;                       // virtual channel concatenation of up-sampled sources (mpn.h: kseg_*)
 #pragma unroll
@@ -845,10 +822,7 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
         const unsigned bi = pcu / HoWo;
         const unsigned rem = pcu - bi * HoWo;
         b_h[q] = (int)(rem / (unsigned)p.Wo);
-        if (EXT) {
-            b_w[q] = (int)(rem - (unsigned)b_h[q] * (unsigned)p.Wo);
-            b_bi[q] = (int)bi;
-        }
+        if (EXT) b_wb[q] = (bi << 16) | (rem - (unsigned)b_h[q] * (unsigned)p.Wo);
         b_ok[q] = ok;
         b_base[q] = (unsigned)(((long)pcu * p.x_sW + u_piece_b * C::V) * TS);
     }
@@ -864,16 +838,19 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
     // dx = -1 / 0 / +1 the tap's column shift), un-swizzled with that ROW's key.
     const int f_off = (lane & 15) * 64 + (((lane >> 4) ^ ((0 - ((lane >> 2) & 3)) & 3)) * 16);
     const int fa_off = wc * C::WTC * 64 + f_off;
-    int fb_off[3][C::MP];
+    // (fragment j sits 16 rows = 1 KiB further on and 16 rows do not change bit 2 of the row index, i.e. the key: one offset per tap
+    // shift, j * 1024 rides in the ds_read's immediate — 3 registers instead of 3 * MP; round 5, after the 256-row extended
+    // instantiation had started to reload spilled gather state from scratch — with a vmcnt(0) — inside its k-loop)
+    int fb_off[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int row = wp * C::WTP + (lane & 15) + d;
+        fb_off[d] = row * 64 + (((lane >> 4) ^ (((row >> 2) & 1) << 1)) * 16);
+    }
     unsigned edge_l = 0u, edge_r = 0u;                            // bit j: the lane's pixel of fragment j sits in the first / last column
 #pragma unroll
     for (int j = 0; j < C::MP; ++j) {
         const int l = wp * C::WTP + j * 16 + (lane & 15);
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int row = l + d;
-            fb_off[d][j] = row * 64 + (((lane >> 4) ^ (((row >> 2) & 1) << 1)) * 16);
-        }
         const unsigned pix = (unsigned)p0 + (unsigned)l;
         const unsigned wo = (pix < P ? pix : 0u) % (unsigned)p.Wo;
         edge_l |= (wo == 0u ? 1u : 0u) << j;
@@ -908,7 +885,7 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
                 for (int q = 0; q < LB; ++q) {
                     const int hh = b_h[q] + dy;
                     const bool ok = b_ok[q] && (unsigned)hh < (unsigned)p.H;
-                    const unsigned src = (unsigned)((b_bi[q] * Hs + (hh >> sh)) * Ws + (b_w[q] >> sh));
+                    const unsigned src = (unsigned)(((int)(b_wb[q] >> 16) * Hs + (hh >> sh)) * Ws + (int)((b_wb[q] & 0xffffu) >> sh));
                     const unsigned voff = ok ? (src * (unsigned)pk.kseg_c + (unsigned)(u_piece_b * C::V)) * TS : 0x80000000u;
                     lds_dma16(voff, rs, so, __builtin_amdgcn_readfirstlane(st + (wave_u * LB + q) * 1024u));
                 }
@@ -935,11 +912,9 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
 #pragma unroll
         for (int i = 0; i < C::MC; ++i)
             fa[i] = *reinterpret_cast<const u32x4_t*>(abase + fa_off + i * 1024);
+        const int off = dx == 0 ? fb_off[0] : (dx == 1 ? fb_off[1] : fb_off[2]);
 #pragma unroll
-        for (int j = 0; j < C::MP; ++j) {
-            const int off = dx == 0 ? fb_off[0][j] : (dx == 1 ? fb_off[1][j] : fb_off[2][j]);
-            fb[j] = *reinterpret_cast<const u32x4_t*>(bbase + off);
-        }
+        for (int j = 0; j < C::MP; ++j) fb[j] = *reinterpret_cast<const u32x4_t*>(bbase + off + j * 1024);
         if (dx != 1) {                                           // outer taps: pixels beyond the left / right border read zeros
             const unsigned edge = dx == 0 ? edge_l : edge_r;
 #pragma unroll
@@ -1007,7 +982,9 @@ __global__ void __launch_bounds__(256, TC > 128 ? 2 : 3) conv_igemm_s3_kernel(co
 }
 
 constexpr int kTP = 128;
+#if MPN_EXP
 bool g_igemm_prof = false;          // tools/kloop_profile.py: route 128-row bf16 launches to the PROF instantiations
+#endif
 
 // Block tile height (output channels).  The k-loop is bound by the DMA/LDS path, so the tallest tile that still
 // fills the chip wins: 256 rows (2 workgroups per CU) for long contractions with enough workgroups, else 128 rows
@@ -1016,9 +993,9 @@ inline int pick_tc(const MpnConvParams& p, long tilesP) {
     const int cout_store = p.Cout_store;
     if (cout_store <= 32) return 32;
     if (cout_store <= 64) return 64;
-    static const long min_blocks = getenv("MPN_TC_MIN_BLOCKS") ? atol(getenv("MPN_TC_MIN_BLOCKS")) : 200;
-    static const long min_blocks256 = getenv("MPN_TC256_MIN_BLOCKS") ? atol(getenv("MPN_TC256_MIN_BLOCKS")) : 400;
-    static const long min_ksteps256 = getenv("MPN_TC256_MIN_KSTEPS") ? atol(getenv("MPN_TC256_MIN_KSTEPS")) : 16;
+    static const long min_blocks = mpn_tune("MPN_TC_MIN_BLOCKS", 200);
+    static const long min_blocks256 = mpn_tune("MPN_TC256_MIN_BLOCKS", 400);
+    static const long min_ksteps256 = mpn_tune("MPN_TC256_MIN_KSTEPS", 16);
     const long ksteps = (long)p.R * p.S * p.Cin / (p.dtype == MPN_F32 ? 16 : 32);
     if (cout_store >= 256 && tilesP * ((cout_store + 255) / 256) >= min_blocks256 && ksteps >= min_ksteps256) return 256;
     const long blocks128 = tilesP * ((cout_store + 127) / 128);
@@ -1026,7 +1003,7 @@ inline int pick_tc(const MpnConvParams& p, long tilesP) {
 }
 
 inline bool conv_uses_s3(const MpnConvParams& p, int tc) {
-    static const bool on = !(getenv("MPN_IGEMM_S3") && atoi(getenv("MPN_IGEMM_S3")) == 0);
+    static const bool on = mpn_tune("MPN_IGEMM_S3", 1) != 0;
     if (!on || p.dtype == MPN_F32 || p.R != 3 || p.S != 3 || p.stride != 1 || p.pad != 1 || tc < 64) return false;
     if (p.nseg > 0 || p.kseg_n > 0) return true;                  // pyramid levels / concatenation members are dense by construction
     return p.H == p.Ho && p.W == p.Wo && p.x_sH == (int64_t)p.W * p.x_sW && p.x_sB == (int64_t)p.H * p.x_sH;
@@ -1034,6 +1011,7 @@ inline bool conv_uses_s3(const MpnConvParams& p, int tc) {
 
 template <typename T, bool OUTF32, bool GENERAL, bool EXT = false>
 int launch_conv_k(const MpnConvParams& p, int tc, long grid, int dbg, hipStream_t st) {
+#if MPN_EXP
     if constexpr (std::is_same<T, bf16_t>::value && !OUTF32 && !EXT) {
         if (g_igemm_prof && tc == 128 && !p.fin_counters) {
             if (conv_uses_s3(p, tc)) hipLaunchKernelGGL((conv_igemm_s3_kernel<T, 128, kTP, false, GENERAL, false, true>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
@@ -1041,6 +1019,7 @@ int launch_conv_k(const MpnConvParams& p, int tc, long grid, int dbg, hipStream_
             return mpn_launch_status();
         }
     }
+#endif
     if constexpr (sizeof(T) == 2) {
         if (conv_uses_s3(p, tc)) {
             if (tc == 256) hipLaunchKernelGGL((conv_igemm_s3_kernel<T, 256, kTP, OUTF32, GENERAL, EXT>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
@@ -1070,7 +1049,7 @@ int launch_conv(const MpnConvParams& p, hipStream_t st) {
     const long tilesC = (p.Cout_store + tc - 1) / tc;
     const long grid = tilesP * tilesC;
     if (grid <= 0 || grid > 0x7fffffffL || P >= 0x7fffffffL) return MPN_E_BADARG;
-    static const int dbg = getenv("MPN_DEBUG_FLAGS") ? atoi(getenv("MPN_DEBUG_FLAGS")) : 0;   // microbenchmark ablations only
+    static const int dbg = (int)mpn_tune("MPN_DEBUG_FLAGS", 0);   // microbenchmark ablations (experiments build only)
     // "plain" = conv (+ BN tile statistics): no per-element epilogue math at all, lighter register footprint
     const bool general = p.scale || p.bias || p.res_mode || p.accumulate || p.act || (p.Cout % tc) != 0 || p.bnb_partial;
     if (conv_needs_ext(p)) {
@@ -1083,9 +1062,14 @@ int launch_conv(const MpnConvParams& p, hipStream_t st) {
 }  // namespace
 
 extern "C" int mpn_debug_igemm_prof(void* buf) {
+#if MPN_EXP
     g_igemm_prof = buf != nullptr;
     unsigned long long* q = (unsigned long long*)buf;
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(d_igemm_prof), &q, sizeof(q));
+#else
+    (void)buf;
+    return MPN_E_UNSUPPORTED;          // the PROF instantiations live in the experiments build only (common.h)
+#endif
 }
 
 extern "C" int mpn_conv_stats_tiles(const MpnConvParams* p) {
@@ -1123,6 +1107,7 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     if (p.kseg_n > 0) {     // virtual concatenation: served by the shared-tile 3x3 kernel only
         MPN_CHECK_ARG(p.kseg_n <= 4 && p.kseg_c > 0 && p.kseg_c % 32 == 0 && p.Cin == p.kseg_n * p.kseg_c && p.mode == 0 && !p.nseg);
         MPN_CHECK_ARG(p.dtype != MPN_F32 && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.H == p.Ho && p.W == p.Wo && p.Cout_store > 32);
+        MPN_CHECK_ARG(p.B < 65536 && p.W < 65536);               // the gather keeps (image, column) in one 32-bit register
         for (int k = 0; k < p.kseg_n; ++k) {
             MPN_CHECK_ARG(p.kseg_x[k] && p.kseg_shift[k] >= 0 && p.kseg_shift[k] < 8 && ((p.H >> p.kseg_shift[k]) << p.kseg_shift[k]) == p.H &&
                           ((p.W >> p.kseg_shift[k]) << p.kseg_shift[k]) == p.W);
@@ -1142,7 +1127,6 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     MPN_CHECK_ARG(!p.res_mask || (p.res_mode == 1 && !p.nseg && p.y_sB == (int64_t)p.Ho * p.Wo * p.y_sP && p.y_sP == p.Cout_store));
     MPN_CHECK_ARG(!(p.stats && (p.bias || p.scale || p.res_mode || p.accumulate || p.act)));
     MPN_CHECK_ARG(!((p.res_mode || p.accumulate) && p.act && p.act != 3));
-    MPN_CHECK_ARG(!p.stats_atomic || (p.stats_atomic == 1 && p.stats && !p.fin_counters && !p.nseg));
     MPN_CHECK_ARG(!p.fin_counters || (((p.stats != nullptr) != (p.bnb_partial != nullptr)) && p.fin_count > 0 && !p.nseg &&
                                       (p.stats ? p.fin_out != nullptr : true)));
     MPN_CHECK_ARG(!p.bnb_partial || (p.bnb_y && p.bnb_mean && p.bnb_invstd && !p.out_f32 && !p.nseg && !p.stats && !p.act &&

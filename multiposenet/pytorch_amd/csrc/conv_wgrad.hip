@@ -679,7 +679,9 @@ __global__ void reduce_partials_small_kernel(const float* __restrict__ ws, int c
     }
 }
 
+#if MPN_EXP
 unsigned long long* g_wgrad_prof = nullptr;        // tools/kloop_profile.py: [workgroups][4 waves][8] cycle sums of the next 128x128 launches
+#endif
 
 inline int pick_tile(int n) { return n > 64 ? 128 : (n > 32 ? 64 : 32); }
 
@@ -701,7 +703,7 @@ inline long wgrad_total_pixels(const MpnWgradParams& p) {
 }
 
 inline bool wgrad_uses_dma(const MpnWgradParams& p) {
-    static const bool use_dma = !(getenv("MPN_WGRAD_NO_DMA") && atoi(getenv("MPN_WGRAD_NO_DMA")));
+    static const bool use_dma = mpn_tune("MPN_WGRAD_NO_DMA", 0) == 0;
     long P = (long)p.B * p.Ho * p.Wo, xb = (long)p.B * p.x_sB;
     if (p.kseg_n > 0) xb = (long)p.B * p.H * p.W * p.kseg_c;
     if (p.nseg > 0) {
@@ -718,8 +720,13 @@ inline bool wgrad_uses_dma(const MpnWgradParams& p) {
 
 // LIN instantiations (linear x addressing): stride-1 convolutions whose output has the input's extent, over a dense x, no virtual concatenation
 inline bool wgrad_lin_ok(const MpnWgradParams& p) {
-    static const bool on = !(getenv("MPN_WGRAD_LIN") && !atoi(getenv("MPN_WGRAD_LIN")));
+    static const bool on = mpn_tune("MPN_WGRAD_LIN", 1) != 0;
     if (p.nseg > 0) return true;
+    // the tap offset moves into the x descriptor (base + tap, num_records = bytes - tap): a NEGATIVE tap lengthens the range by up to
+    // (pad W + pad) pixels, and the descriptor holds 2^31 - 1 bytes at most — beyond that the launch takes the gather kernel instead of
+    // a clamped descriptor that would zero-fill valid rows at the tail
+    const int64_t reach = (int64_t)p.B * p.x_sB * 2 + ((int64_t)p.pad * p.W + p.pad) * p.x_sW * 2;
+    if (reach >= 0x7fffffffLL) return false;
     return on && p.kseg_n == 0 && p.stride == 1 && p.Ho == p.H && p.Wo == p.W && p.x_sH == (int64_t)p.W * p.x_sW && p.x_sB == (int64_t)p.H * p.x_sH;
 }
 
@@ -734,7 +741,7 @@ inline void wgrad_tiles(const MpnWgradParams& p, int& tm, int& tn) {
     // measured SLOWER (3x3 256->256 @60x60: 243 vs 208 us, 512->256 @120x120: 1595 vs 1431 us): with two workgroups
     // per CU the transpose reads are no longer hidden and the slice count (partial-sum traffic) doubles.  Kept behind
     // MPN_WGRAD_TM256_MIN_STEPS (minimum k-steps per workgroup) for experiments, off by default.
-    static const long min_steps = getenv("MPN_WGRAD_TM256_MIN_STEPS") ? atol(getenv("MPN_WGRAD_TM256_MIN_STEPS")) : (1L << 40);
+    static const long min_steps = mpn_tune("MPN_WGRAD_TM256_MIN_STEPS", 1L << 40);
     if (p.Cin >= 256 && tn == 128) {
         const long tiles = (long)((p.Cin + 255) / 256) * ((p.Cout + 127) / 128) * p.R * p.S;
         const long chunks = (kWgradTarget + tiles - 1) / tiles;
@@ -756,7 +763,7 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st, bool reduce = true) {
     const long grid = tilesM * tilesN * p.R * p.S * p.chunks;
     if (grid <= 0 || grid > 0x7fffffffL || P >= 0x7fffffffL) return MPN_E_BADARG;
     // ablations for tools/ (results are WRONG with either bit): 1 = no reduction launch, 2 = the slices do not store their partials
-    static const int ablate = getenv("MPN_WGRAD_ABLATE") ? atoi(getenv("MPN_WGRAD_ABLATE")) : 0;
+    static const int ablate = (int)mpn_tune("MPN_WGRAD_ABLATE", 0);      // experiments build only
     if ((ablate & 2) && p.chunks > 1) chunk_pixels |= (1L << 62);
     if ((ablate & 1) && p.chunks > 1) reduce = false;
     int rc;
@@ -769,10 +776,13 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st, bool reduce = true) {
         else if (tn == 128) hipLaunchKernelGGL((KERNEL<64, 128>), g, blk, 0, st, p, chunk_pixels);                       \
         else hipLaunchKernelGGL((KERNEL<64, 64>), g, blk, 0, st, p, chunk_pixels)
         const bool lin = wgrad_lin_ok(p);
+#if MPN_EXP
         if (g_wgrad_prof && p.nseg == 0 && p.dtype == MPN_BF16 && tm == 128 && tn == 128) {
             if (lin) hipLaunchKernelGGL((conv_wgrad_dma_lin_prof_kernel<128, 128>), g, blk, 0, st, p, chunk_pixels, g_wgrad_prof);
             else hipLaunchKernelGGL((conv_wgrad_dma_prof_kernel<128, 128>), g, blk, 0, st, p, chunk_pixels, g_wgrad_prof);
-        } else if (p.nseg == 0 && lin) {
+        } else
+#endif
+        if (p.nseg == 0 && lin) {
             if (p.dtype == MPN_F16) { MPN_WGRAD_DMA_LAUNCH(conv_wgrad_dma_lin_f16_kernel); }
             else { MPN_WGRAD_DMA_LAUNCH(conv_wgrad_dma_lin_kernel); }
         } else if (p.nseg > 0) {
@@ -800,7 +810,15 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st, bool reduce = true) {
 
 }  // namespace
 
-extern "C" int mpn_debug_wgrad_prof(void* buf) { g_wgrad_prof = (unsigned long long*)buf; return 0; }
+extern "C" int mpn_debug_wgrad_prof(void* buf) {
+#if MPN_EXP
+    g_wgrad_prof = (unsigned long long*)buf;
+    return 0;
+#else
+    (void)buf;
+    return MPN_E_UNSUPPORTED;          // the PROF instantiations live in the experiments build only (common.h)
+#endif
+}
 
 extern "C" int mpn_conv_wgrad_seg_plan(MpnWgradParams* p) {
     if (!p || p->nseg <= 0 || p->nseg > 5) return MPN_E_BADARG;
@@ -827,13 +845,13 @@ extern "C" int mpn_conv_wgrad_chunks(const MpnWgradParams* p) {
     wgrad_tiles(*p, tm, tn);
     const long tiles = (long)((p->Cin + tm - 1) / tm) * ((p->Cout + tn - 1) / tn) * p->R * p->S;
     const long P = wgrad_total_pixels(*p);
-    static const long target = getenv("MPN_WGRAD_TARGET") ? atol(getenv("MPN_WGRAD_TARGET")) : kWgradTarget;
-    static const long minpix = getenv("MPN_WGRAD_MINPIX") ? atol(getenv("MPN_WGRAD_MINPIX")) : 512;
+    static const long target = mpn_tune("MPN_WGRAD_TARGET", kWgradTarget);
+    static const long minpix = mpn_tune("MPN_WGRAD_MINPIX", 512);
     // ~2 workgroups per CU (long slices run near peak, partial-sum traffic dominates beyond) and NEVER one more than that: rounding the
     // slice count up put 540 workgroups on the 512 slots of the 3x3 256-channel layers — the 28 that share a CU three ways finish last,
     // and in isolation the launch takes 15 - 20 % longer (3x3 256->256 @30x30 64 -> 53 us, @60x60 195 -> 161, 512->256 @120x120
     // 1 374 -> 1 216; in the step, where the other stream fills the tail, neutral: profiles/r04_kloop_phase_profile.txt).  MPN_WGRAD_CEIL=1: the old rounding
-    static const bool round_up = getenv("MPN_WGRAD_CEIL") && atoi(getenv("MPN_WGRAD_CEIL"));
+    static const bool round_up = mpn_tune("MPN_WGRAD_CEIL", 0) != 0;
     long want = round_up ? (target + tiles - 1) / tiles : target / tiles;
     const long maxc = (P + minpix - 1) / minpix;       // keep >= 512 pixels per slice
     if (want > maxc) want = maxc;
@@ -848,6 +866,8 @@ extern "C" int mpn_conv_wgrad(const MpnWgradParams* pp, void* stream) {
     MPN_CHECK_ARG(p.dw && mpn_dtype_ok(p.dtype) && p.B > 0 && p.Cin > 0 && p.Cout > 0);
     if (p.nseg > 0) {
         MPN_CHECK_ARG(p.nseg <= 5 && wgrad_uses_dma(p) && p.stride == 1 && p.R == p.S && 2 * p.pad == p.R - 1);
+        for (int l = 0; l < p.nseg; ++l)         // pyramid levels always take the linear-addressing kernel: same descriptor reach rule
+            if (((int64_t)p.B * p.seg_H[l] * p.seg_W[l] + (int64_t)p.pad * p.seg_W[l] + p.pad) * p.x_sW * 2 >= 0x7fffffffLL) return MPN_E_UNSUPPORTED;
         MPN_CHECK_ARG(p.seg_chunk_pixels > 0 && p.seg_chunk_pixels % 32 == 0 && p.seg_chunk0[0] == 0 && p.seg_chunk0[p.nseg] == p.chunks);
         for (int l = 0; l < p.nseg; ++l) MPN_CHECK_ARG(p.seg_x[l] && p.seg_dy[l] && p.seg_H[l] > 0 && p.seg_W[l] > 0);
     } else {

@@ -48,6 +48,9 @@ class GradReducer(object):
         self.launch_stream = None      # set by the engine when weight gradients are produced on a side stream
         self.pre_launch = None         # engine hook: hand over side-stream work still waiting for a fork point
         self._trainable_sig = tuple(p.requires_grad for p in arena.params)
+        self.bucket_mb = float(bucket_mb)
+        self.measure = False           # bench.py: bracket finish()'s waits with a pair of timing events (exposed_ms)
+        self._ev = None
 
     def _build(self):
         ar = self.arena
@@ -134,6 +137,11 @@ class GradReducer(object):
         for bk in self.buckets:
             if bk["pending"] >= 0:
                 self._launch(bk)
+        if self.measure and torch.cuda.is_available():
+            # bench.py: GPU time the launch stream spends in the waits below = all-reduce time NOT hidden behind backward
+            if self._ev is None:
+                self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._ev[0].record()
         for h, view in self.handles:
             h.wait()
             if isinstance(view, tuple):             # host-staged bucket (gloo with device gradients)
@@ -141,7 +149,16 @@ class GradReducer(object):
                 view.copy_(host.mul_(1.0 / self.world))
             elif not self.use_avg:
                 view.mul_(1.0 / self.world)
+        if self.measure and self._ev is not None:
+            self._ev[1].record()
         self.handles = []
+
+    def exposed_ms(self):
+        """GPU time between the end of backward on the launch stream and the completion of the last collective, for the most
+        recent step (needs ``measure = True`` before that step and a device synchronisation after it)."""
+        if self._ev is None:
+            return None
+        return float(self._ev[0].elapsed_time(self._ev[1]))
 
 
 def broadcast_state(model, process_group=None, src=0):

@@ -37,11 +37,7 @@ class Ctx(object):
         self.side_pending = []   # closures waiting for the next fork point (Engine.fork_every > 1)
         self.wt_ready = None     # event: the transposed weight copies (made on the side stream) are complete
         self.bnb = {}            # id(BN output Act) -> per-tile backward statistics produced by the launch that completed its gradient
-        self.side_deferred = []  # side-stream closures held back for later fork points (Engine.side_defer)
-        self.side_count = 0
         self.fwd_side_join = False   # forward work is in flight on the side stream (Engine.det_pyramid): join before it is consumed
-        self.stat_acc = None     # int64 [total BatchNorm channels, 2]: this pass's atomic statistics accumulators (Engine._stat_acc)
-        self.stat_acc_next = 0
         self.lazy_res = {}       # id(Act) -> (dz, mask bits): shortcut gradient dz * (z > 0) NOT materialised; the convolution whose
                                  # input gradient completes that Act adds it in its epilogue (Engine.defer_shortcut_grad)
 
@@ -84,11 +80,6 @@ class Engine(object):
         # side-stream work is handed over in groups of `fork_every` layers (one event record / wait per group): a captured
         # hipGraph pays for every cross-stream edge, the eager tape does not care much
         self.fork_every = max(1, int(os.environ.get("MPN_SIDE_FORK_EVERY", "1")))
-        # scheduling experiment: hold back the first `side_defer` weight-gradient closures of a backward pass (the heads' MFMA-bound
-        # ones, which otherwise compete with the heads' equally MFMA-bound dgrads) and release `side_release` of them per later
-        # fork point, beside the HBM-bound BatchNorm passes of the backbone
-        self.side_defer = int(os.environ.get("MPN_SIDE_DEFER", "0"))
-        self.side_release = max(1, int(os.environ.get("MPN_SIDE_RELEASE", "1")))
         # the RetinaNet towers share their weights over p3..p7: one launch per layer over the whole pyramid instead of one per level
         self.pyramid_towers = os.environ.get("MPN_PYRAMID_TOWERS", "1") != "0"
         # BatchNorm-backward statistics ride in the epilogue of the dgrad launch that completes dz (no separate reduction pass)
@@ -108,16 +99,6 @@ class Engine(object):
         # torch.cat((up8(q5), up4(q4), up2(q3), q2), 1) -> conv2 (posenet.py:311-315): the 512-channel tensor is never written; conv2's
         # forward and weight-gradient launches gather from the four members, its input gradient lands in q2's gradient directly
         self.virtual_concat = os.environ.get("MPN_VIRTUAL_CONCAT", "1") != "0"
-        # training forward, OFF by default (measured neutral): the conv epilogue adds its tile statistics to per-channel 64-bit
-        # fixed-point accumulators with integer atomics (order-independent, deterministic) and bn_act derives the coefficients in its
-        # prologue, so the finalize launch between conv and bn_act — 16 us of dependent kernel boundary per BatchNorm layer, 1.6 ms a
-        # step by ablation — is gone.  But gfx950 carries every global atomic out at the memory side: even packed into whole lines
-        # and issued before the tile's stores the atomics cost what the launches cost (layers of 65 .. 1000 pixel tiles: 37.74 vs
-        # 37.75 ms/step; every layer: +0.3 .. +2.1 ms depending on the form — profiles/r04_bn_atomic_stats_ab.txt)
-        self.bn_atomic = os.environ.get("MPN_BN_ATOMIC_STATS", "0") != "0"
-        self.bn_atomic_min_tiles = int(os.environ.get("MPN_BN_ATOMIC_MIN_TILES", "65"))
-        self.bn_atomic_max_tiles = int(os.environ.get("MPN_BN_ATOMIC_MAX_TILES", "1000"))
-        self._bn_channels = None
 
     def side_stream(self, device):
         """Second HIP stream for weight/bias gradients.  They are off the backward critical path (only the
@@ -127,7 +108,7 @@ class Engine(object):
         if not self.overlap_wgrad or device.type != "cuda":
             return None
         if self._side is None:
-            self._side = torch.cuda.Stream(device=device, priority=int(os.environ.get("MPN_SIDE_PRIORITY", "0")))
+            self._side = torch.cuda.Stream(device=device)
         return self._side
 
     def _on_side(self, ctx, device, keep, fn, torch_ops=False):
@@ -139,14 +120,7 @@ class Engine(object):
             fn()
             return
         ctx.side_keep.append(keep)
-        ctx.side_count += 1
-        if ctx.side_count <= self.side_defer and self.m._reducer is None:
-            ctx.side_deferred.append((fn, torch_ops))
-            return
         ctx.side_pending.append((fn, torch_ops))
-        if ctx.side_deferred:
-            ctx.side_pending.extend(ctx.side_deferred[:self.side_release])
-            del ctx.side_deferred[:self.side_release]
         if len(ctx.side_pending) >= self.fork_every:
             self.flush_side(ctx, device)
 
@@ -283,35 +257,12 @@ class Engine(object):
             return None
         return (bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1, bn.eps)
 
-    def _stat_acc(self, ctx, device):
-        """Allocator of atomic statistics accumulators for this pass (ops.conv_forward(stat_acc=...)): slices of ONE zeroed int64
-        buffer sized for every BatchNorm channel of the model, zeroed by one fill launch when the pass first needs it (a recorded
-        step re-zeroes it on every replay).  None when the atomic path is off."""
-        if not self.bn_atomic:
-            return None
-
-        def take(tiles, C):
-            if tiles < self.bn_atomic_min_tiles or tiles > self.bn_atomic_max_tiles:
-                return None
-            if self._bn_channels is None:
-                self._bn_channels = sum(m.num_features for m in self.m.modules() if isinstance(m, torch.nn.BatchNorm2d))
-            if ctx.stat_acc is None or ctx.stat_acc_next + C > ctx.stat_acc.shape[0]:
-                ctx.stat_acc = torch.empty((max(self._bn_channels, C), 2), dtype=torch.int64, device=device)
-                call("mpn_fill_f32", ops.ptr(ctx.stat_acc), 0.0, ctx.stat_acc.numel() * 2, ops.stream_ptr())
-                ctx.stat_acc_next = 0
-                ctx.keep.append(ctx.stat_acc)
-            a = ctx.stat_acc[ctx.stat_acc_next: ctx.stat_acc_next + C]
-            ctx.stat_acc_next += C
-            return a
-        return take
-
     def conv(self, ctx, x, layer, act=0, res=None, res_mode=0, stats=False, out_f32=False, tag="", bn=None):
         O, I, R, S, stride, pad = _geom(layer)
         bias = layer.bias
         y, st = ops.conv_forward(x, self.w_fwd(layer), O, R, S, stride, pad, bias=bias.data if bias is not None else None,
                                  act=act, res=res, res_mode=res_mode, want_stats=stats, out_f32=out_f32, tag=tag,
-                                 bn_fin=self._bn_fin(bn) if stats else None,
-                                 stat_acc=self._stat_acc(ctx, x.t.device) if (stats and bn is not None) else None)
+                                 bn_fin=self._bn_fin(bn) if stats else None)
         y.relu_out = act == 1
         if ctx.train:
             y.needs_grad = bool(x.needs_grad or layer.weight.requires_grad or (bias is not None and bias.requires_grad)
@@ -487,22 +438,17 @@ class Engine(object):
     def bn(self, ctx, y, stats, layer, relu, res=None, tag=""):
         train_stats = layer.training
         want_mask = bool(self.bn_mask_bits and ctx.train and relu and res is not None)
-        z = None
         if train_stats:
             momentum = layer.momentum if layer.momentum is not None else 0.1
             if isinstance(stats, ops.BNState):         # the conv launch finalized in place
                 st = stats
-            elif isinstance(stats, ops.StatAcc):       # atomic statistics: coefficients + normalise in one launch
-                z, st = ops.bn_act_acc(y, stats, layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var,
-                                       momentum, layer.eps, relu, res=res, tag=tag, want_mask=want_mask)
             else:
                 st = ops.bn_finalize_train(stats, y.P, layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var,
                                            momentum, layer.eps)
             ctx.bn_train_ran = True
         else:
             st = ops.bn_finalize_eval(layer.weight.data, layer.bias.data, layer.running_mean, layer.running_var, layer.eps)
-        if z is None:
-            z = ops.bn_act(y, st, relu, res=res, tag=tag, want_mask=want_mask)
+        z = ops.bn_act(y, st, relu, res=res, tag=tag, want_mask=want_mask)
         if ctx.train:
             z.needs_grad = bool(y.needs_grad or layer.weight.requires_grad or layer.bias.requires_grad
                                 or (res is not None and res.needs_grad))
@@ -749,8 +695,7 @@ class Engine(object):
             z, _ = ops.conv_forward(xa, wp, 64, 7, 1, 2, 0, cin=32, x_geom=geom, out_hw=(Ho, Wo), scale=bst.scale, bias=bst.shift, act=1)
             return self.maxpool(ctx, z)
         y, st = ops.conv_forward(xa, wp, 64, 7, 1, 2, 0, cin=32, x_geom=geom, out_hw=(Ho, Wo), want_stats=bn_train,
-                                 bn_fin=self._bn_fin(f.bn1) if bn_train else None,
-                                 stat_acc=self._stat_acc(ctx, img.device) if bn_train else None)
+                                 bn_fin=self._bn_fin(f.bn1) if bn_train else None)
         if ctx.train and w.requires_grad:
             y.needs_grad = True
             self._note_use(ctx, w)
@@ -819,7 +764,7 @@ class Engine(object):
             h["p3s"], _ = self.conv(ctx, h["p3"], f.toplayer2)
         h = {}
         dev = c5.t.device
-        mode = self.det_pyramid_side if (self.side_defer == 0 and self.side_stream(dev) is not None) else 0
+        mode = self.det_pyramid_side if self.side_stream(dev) is not None else 0
         if mode:
             # Forward fork: this pyramid feeds only the detection head, which runs after the keypoint head — so it runs on the side
             # stream under the keypoint head's launches and the detection head joins (join_forward_side).  P6 / P7 alone are 32 - 64
@@ -967,8 +912,6 @@ class Engine(object):
         while tape:
             tape.pop()()
         if side is not None:
-            ctx.side_pending.extend(ctx.side_deferred)
-            ctx.side_deferred = []
             self.flush_side(ctx, dev)
             gpu_op(torch.cuda.current_stream(dev).wait_stream, side)      # join: parameter gradients are complete
         ctx.grads.clear()

@@ -131,17 +131,15 @@ class Tester(object):
         from ..training.trainer import LogBook, RunningStat, Stopwatch, _scalar_proxy
         if self.val_data is None or self.batch_processor is None:
             raise ValueError('Tester.val() needs the val_data and batch_processor given to the constructor')
-        was_training = self.model.training
-        bn_modes = [(m, m.training) for m in self.model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        modes = [(m, m.training) for m in self.model.modules()]      # EVERY module's mode (a PRN Dropout set to eval under a training root …)
         self.model.eval()
         was_lazy = losses.set_lazy_log(True)          # build_loss's log values: asynchronous proxies, read when a block is printed
         try:
             return self._val_loop(LogBook, RunningStat, Stopwatch, _scalar_proxy)
         finally:
             losses.set_lazy_log(was_lazy)
-            self.model.train(was_training)            # the modes the caller had (the reference leaves the model in eval mode; a
-            for m, mode in bn_modes:                  # Trainer calling val() between epochs must get its BatchNorm modes back)
-                m.train(mode)
+            for m, mode in modes:                     # the modes the caller had — a deliberate divergence: the reference
+                m.training = mode                     # leaves the model in eval mode; a Trainer calling val() between epochs must get its modes back
 
     def _val_loop(self, LogBook, RunningStat, Stopwatch, _scalar_proxy):
         book, seen = LogBook(), RunningStat()

@@ -159,7 +159,7 @@ class _KernelEvents(object):
 KERNEL_EVENTS = _KernelEvents()
 
 _ws = {}
-WS_EPOCH = 0          # graph.py sets a unique value while it captures: the captured launches then own their scratch buffers
+WS_EPOCH = 0          # replay.py sets a unique value while it records: the recorded launches then own their scratch buffers
 
 
 def take_epoch_workspaces(epoch):
@@ -398,7 +398,7 @@ def conv_out_hw(H, W, R, S, stride, pad):
 def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, res=None, res_mode=0,
                  want_stats=False, out_f32=False, out=None, accumulate=False, mode=0, out_hw=None,
                  cin=None, x_geom=None, y_geom=None, cout_store=None, needs_grad=False, tag="", bnb=None, bn_fin=None, res_mask=None,
-                 stat_acc=None, _cls=None):
+                 _cls=None):
     """Implicit-GEMM convolution.  x: Act.  w: compute-dtype tensor laid out [Cout][R][S][Cin].
 
     mode 0 = forward gather, mode 1 = dgrad gather (then ``out_hw`` is the input-gradient size and
@@ -409,7 +409,7 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
     dt = x.t.dtype
     if (DGRAD_S2_CLASSES and _cls is None and mode == 1 and stride == 2 and not out_f32
             and res is None and not want_stats and bias is None and scale is None and act == 0 and x_geom is None and y_geom is None
-            and out_hw is not None):
+            and out_hw is not None and cout_store is None):
         if R == 3 and S == 3 and pad == 1:
             return _conv_dgrad_s2_classes(x, w, Cout, out_hw, cin, out, accumulate, bnb, needs_grad, tag)
         if R == 1 and S == 1 and pad == 0 and accumulate and bnb is None and out is not None:
@@ -438,6 +438,8 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
             p.y_sB, p.y_sP = Ho * Wo * out.Cs, out.Cs
         else:       # parity class (a, c) of a stride-2 input gradient (mpn.h: y_step): output pixel (i, j) -> (2 i + a, 2 j + c) of `out`
             ca, cc_, p.y_H, p.y_W = _cls[0], _cls[1], out.H, out.W
+            assert out.t.dtype == odt and out.B == x.B and out.Cs == round_up(Cout, 32) and cout_store is None, "class launch: output tensor mismatch"
+            assert 2 * (Ho - 1) + ca < out.H and 2 * (Wo - 1) + cc_ < out.W, "class launch: class grid exceeds the output"
             p.y_step, p.y_oh, p.y_ow = 2, ca, cc_
             if len(_cls) > 4 and _cls[4] == 1:          # 1x1 filter: its only tap
                 p.w_taps, p.wtap0, p.wtap_dr, p.wtap_ds = 1, 0, 0, 0
@@ -475,16 +477,9 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
     keep = None
     if want_stats:
         tiles = call("mpn_conv_stats_tiles", ctypes.byref(p))
-        acc = stat_acc(tiles, Cout) if stat_acc is not None else None
-        if acc is not None:
-            # atomic statistics (mpn.h: stats_atomic): every workgroup adds its tile's (sum, sum^2) to ONE pair of fixed-point
-            # accumulators per channel; bn_act_acc derives the coefficients itself — no partial table, no finalize launch
-            stats = StatAcc(acc, x.B * Ho * Wo)
-            p.stats, p.stats_atomic = acc.data_ptr(), 1
-        else:
-            stats = torch.empty((tiles, Cout, 2), dtype=torch.float32, device=dev)
-            p.stats = stats.data_ptr()
-        if acc is None and bn_fin is not None and fin_in_launch(tiles):
+        stats = torch.empty((tiles, Cout, 2), dtype=torch.float32, device=dev)
+        p.stats = stats.data_ptr()
+        if bn_fin is not None and fin_in_launch(tiles):
             # the last workgroup of every channel tile turns the tile partials into the BatchNorm coefficients (no finalize launch):
             # the BNState comes back in the stats slot
             gamma, beta, rm, rv, momentum, eps = bn_fin
@@ -697,14 +692,6 @@ def fin_counters(device):
     return t
 
 
-class StatAcc(object):
-    """Atomic batch statistics of one BatchNorm input: ``acc`` = int64 [C, 2] fixed-point totals (mpn.h: stats_atomic)."""
-    __slots__ = ("acc", "count")
-
-    def __init__(self, acc, count):
-        self.acc, self.count = acc, count
-
-
 class BNState(object):
     __slots__ = ("mean", "invstd", "scale", "shift")
 
@@ -738,20 +725,6 @@ def bn_act(y, st, relu, res=None, needs_grad=False, tag="", want_mask=False):
     call("mpn_bn_act_forward", ptr(y.t), ptr(res.t) if res is not None else None, ptr(z.t), ptr(st.scale), ptr(st.shift),
          y.P, y.C, y.Cs, 1 if relu else 0, dtype_code(y.t.dtype), ptr(z.mask), stream_ptr())
     return z
-
-
-def bn_act_acc(y, sacc, gamma, beta, rm, rv, momentum, eps, relu, res=None, needs_grad=False, tag="", want_mask=False):
-    """Training-mode z = act(bn(y) [+ res]) from atomic statistics (mpn.h: mpn_bn_act_acc_forward): coefficients, running
-    statistics and the normalise pass in ONE launch.  Returns (z, BNState)."""
-    assert sacc.count == y.P and tuple(sacc.acc.shape) == (y.C, 2) and sacc.acc.is_contiguous()
-    st = BNState(y.C, y.t.device)
-    z = Act(torch.empty_like(y.t), y.C, needs_grad, tag)
-    if want_mask and relu:
-        z.mask = torch.empty((y.P, y.Cs // (4 if y.t.dtype == torch.float32 else 8)), dtype=torch.uint8, device=y.t.device)
-    call("mpn_bn_act_acc_forward", ptr(y.t), ptr(res.t) if res is not None else None, ptr(z.t), y.P, y.C, y.Cs, 1 if relu else 0,
-         dtype_code(y.t.dtype), ptr(z.mask), ptr(sacc.acc), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), momentum, eps,
-         ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), stream_ptr())
-    return z, st
 
 
 def masked_copy(dz, mask_bits, out):
@@ -923,8 +896,16 @@ def gather_dets(dets, keep):
     return boxes, scores
 
 
-_NMS_PRE_TOPN_ENV = int(os.environ.get("MPN_NMS_PRE_TOPN", "0"))      # default cap of candidates per image entering NMS (0 = none, as the reference)
 _NMS_WARNED = []
+
+
+def nms_pre_topn_env():
+    """MPN_NMS_PRE_TOPN, read at CALL time: cap of candidates per image entering NMS when the caller passes none.  Unset / 0 = no cap —
+    the reference's behaviour (posenet.py:269-285 hands every candidate above the score threshold to nms); there is NO default cap."""
+    try:
+        return max(0, int(os.environ.get("MPN_NMS_PRE_TOPN", "0")))
+    except ValueError:
+        return 0
 
 
 def detect_batched(boxes, scores, score_thresh, iou_thresh, mode=0, ws_limit=4 << 30, padded=False, pre_nms_top_n=None):
@@ -946,8 +927,8 @@ def detect_batched(boxes, scores, score_thresh, iou_thresh, mode=0, ws_limit=4 <
             return torch.zeros((B, 0, 4), dtype=torch.float32, device=dev), torch.zeros((B, 0), dtype=torch.float32, device=dev), [0] * B
         return [(None, None)] * B
     ncand = nmax
-    if pre_nms_top_n is None and _NMS_PRE_TOPN_ENV > 0:
-        pre_nms_top_n = _NMS_PRE_TOPN_ENV
+    if pre_nms_top_n is None and nms_pre_topn_env() > 0:
+        pre_nms_top_n = nms_pre_topn_env()
     top = int(pre_nms_top_n) if pre_nms_top_n else 0
     if top == 0 and nmax > 32768 and not _NMS_WARNED:
         # the reference's behaviour (every candidate above the score threshold enters the suppression) costs an N x N / 64 mask per image:

@@ -15,7 +15,7 @@ captured hipGraph does not help on this stack (ROCm 7.0 replays a graph node by 
   * every later call re-issues the list — a tight loop of ~2 300 foreign calls (~6 us each) — after copying the new
     batch into the recorded input tensors.
 
-Same interface as ``training.batch_processor.train_step`` / ``graph.GraphedTrainStep``:
+Same interface as ``training.batch_processor.train_step``:
 
     step = ReplayedTrainStep(model, optimizer)
     loss, saved_for_log = step(inputs, gts)
@@ -253,6 +253,16 @@ class ReplayedTrainStep(object):
         ent.sig = self._state_sig()
         self._entries[key] = ent
         while len(self._entries) > self.max_entries:          # least recently used recording out (its pool is released)
-            self._drop(next(iter(self._entries)))
+            old = next(iter(self._entries))
+            self._drop(old)
+            self._seen.pop(old, None)                          # ... and forgotten: a signature that returns pays its eager step(s) again
             self.evictions += 1
+        if len(self._seen) > 8 * self.max_entries:             # signatures seen once and never again must not accumulate either
+            for k in [k for k in self._seen if k not in self._entries][: len(self._seen) - 4 * self.max_entries]:
+                del self._seen[k]
+        if self.evictions >= 4 * self.max_entries and "thrash" not in self._warned:
+            self._warned.add("thrash")
+            import warnings
+            warnings.warn("recorded train step: %d recordings evicted with %d slots — every eviction re-records a whole step's memory pool; "
+                          "raise MPN_REPLAY_MAX_ENTRIES / max_entries, a larger anno_bucket, or fixed input shapes" % (self.evictions, self.max_entries))
         return ent

@@ -53,7 +53,7 @@ _OPTIONS = OrderedDict([
     ('print_freq', 20), ('use_tensorboard', False), ('visualization_fn', None),
 ])
 _EXTRA_OPTIONS = OrderedDict([
-    ('launch', 'replay'),        # 'replay' (recorded launch list) | 'graph' (captured hipGraph) | 'eager' (Python tape)
+    ('launch', 'replay'),        # 'replay' (recorded launch list) | 'eager' (Python tape)
     ('lazy_log', True),          # log values / loss fetched asynchronously, materialised when a line is printed
 ])
 
@@ -244,13 +244,11 @@ class _Stepper(object):
         self.clip = params.max_grad_norm if not math.isinf(params.max_grad_norm) else None
         self.fast = None
         fused = type(optimizer).__name__ == 'FusedAdam' and hasattr(model, '_engine')
-        if fused and self.clip is None and params.launch in ('replay', 'graph'):
-            if params.launch == 'graph':
-                from ..graph import GraphedTrainStep
-                self.fast = GraphedTrainStep(model, optimizer)
-            else:
-                from ..replay import ReplayedTrainStep
-                self.fast = ReplayedTrainStep(model, optimizer)
+        if params.launch not in ('replay', 'eager'):
+            raise ValueError("TrainParams.launch must be 'replay' or 'eager', got %r" % (params.launch,))
+        if fused and self.clip is None and params.launch == 'replay':
+            from ..replay import ReplayedTrainStep
+            self.fast = ReplayedTrainStep(model, optimizer)
 
     def __call__(self, inputs, gts):
         if self.fast is not None:

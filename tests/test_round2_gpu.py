@@ -168,62 +168,6 @@ def _train_setup(layers, dtype, B, S, seed=50):
     return m, [[img, "train_both"]], ["train_both", heat, wgt, anno]
 
 
-def test_graphed_training_step_is_bit_identical_to_the_eager_tape():
-    """Six steps through GraphedTrainStep (two eager, capture, four replays) leave parameters, Adam moments, BN running
-    statistics and every logged loss bit-identical to six eager steps from the same state."""
-    from multiposenet.pytorch_amd.graph import GraphedTrainStep
-    from multiposenet.pytorch_amd.optim import FusedAdam
-    from multiposenet.pytorch_amd.training.batch_processor import train_step
-    m, inputs, gts = _train_setup(50, torch.bfloat16, 4, 128)
-    state0 = {k: v.clone() for k, v in m.state_dict().items()}
-    results = []
-    for graphed in (False, True):
-        m.load_state_dict(state0)
-        opt = FusedAdam(m, lr=1e-3)
-        stepper = GraphedTrainStep(m, opt) if graphed else None
-        logs = []
-        for i in range(6):
-            loss, log = stepper(inputs, gts) if graphed else train_step(m, opt, inputs, gts)
-            logs.append((float(loss), [float(v) for v in log.values()]))
-        torch.cuda.synchronize()
-        if graphed:
-            assert stepper.replays == 4
-        assert opt.step_count() == 6
-        results.append((m._arena.flat.clone(), opt._m.clone(), opt._v.clone(),
-                        {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}, logs))
-    (p0, m0, v0, bn0, l0), (p1, m1, v1, bn1, l1) = results
-    assert l0 == l1, "losses differ between eager and graphed steps: %s vs %s" % (l0, l1)
-    assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
-    assert all(torch.equal(bn0[k], bn1[k]) for k in bn0)
-    assert l0[0][0] != l0[5][0] and all(np.isfinite(x[0]) for x in l0)
-    report("hipGraph step (R50 128x128 B=4 bf16): 6 steps bit-identical to the eager tape, losses %s" % [round(x[0], 5) for x in l1])
-
-
-def test_graphed_step_follows_learning_rate_changes_and_new_inputs():
-    from multiposenet.pytorch_amd.graph import GraphedTrainStep
-    from multiposenet.pytorch_amd.optim import FusedAdam
-    from multiposenet.pytorch_amd.training.batch_processor import train_step
-    m, inputs, gts = _train_setup(50, torch.bfloat16, 2, 64, seed=60)
-    _, inputs_b, gts_b = _train_setup(50, torch.bfloat16, 2, 64, seed=70)
-    state0 = {k: v.clone() for k, v in m.state_dict().items()}
-    outs = []
-    for graphed in (False, True):
-        m.load_state_dict(state0)
-        m.train()
-        opt = FusedAdam(m, lr=1e-3)
-        stepper = GraphedTrainStep(m, opt, eager_steps=1) if graphed else None
-        for i in range(5):
-            if i == 3:
-                opt.param_groups[0]["lr"] = 1e-5           # what ReduceLROnPlateau does between epochs
-            a, b = (inputs, gts) if i % 2 == 0 else (inputs_b, gts_b)       # fresh tensors every call
-            a = [[a[0][0].clone(), a[0][1]]]
-            b = [b[0]] + [x.clone() for x in b[1:]]
-            stepper(a, b) if graphed else train_step(m, opt, a, b)
-        torch.cuda.synchronize()
-        outs.append(m._arena.flat.clone())
-    assert torch.equal(outs[0], outs[1])
-
-
 def test_fused_adam_state_interchanges_with_torch_adam_on_the_device():
     """Take 2 steps with FusedAdam, hand its state_dict to torch.optim.Adam (and back): the third step of both optimizers
     moves the parameters identically (<= 1e-7 abs: same fp32 formula, different association)."""

@@ -93,38 +93,81 @@ def test_grad_reducer_schedule_for_r101_covers_every_trainable_element_once_in_r
 
 
 # ------------------------------------------------------------------------------------------------ code-object resource gate
+DTYPES = ("t", "DF16_", "f")          # bf16 storage, _Float16, float: the three arithmetic types BASELINE's configs run on (cfg3 / cfg5 / cfg2)
+
+
 def _hot_kernels():
-    """(mangled-name fragment, minimum waves per SIMD the schedule was tuned for, LDS bytes or None) — DESIGN.md section 3."""
+    """(mangled-name fragment, minimum waves per SIMD the schedule was tuned for, LDS bytes or None) — DESIGN.md section 3.
+    Round 5: every entry for every element type it is instantiated for (round 4 looked at bf16 only, and two BASELINE configs ran on
+    kernels the gate did not see)."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from codeobj import mangled
     hot = []
-    for k in ("conv_igemm_kernel", "conv_igemm_s3_kernel"):
+    for dt in DTYPES:
         for gen in (False, True):
-            hot.append((mangled(k, "t", 128, 128, False, gen, False, False), 3, 49152))     # 3 workgroups / CU (LDS: 3 x 48 KB)
-            hot.append((mangled(k, "t", 256, 128, False, gen, False, False), 2, 73728))     # 2 workgroups / CU
-            hot.append((mangled(k, "t", 64, 128, False, gen, False, False), 3, 36864))
-    # conv2 through the virtual concatenation (extended epilogue, one launch per pass): 6 VGPRs / 27 SGPRs spilled in its prologue
-    # and epilogue, none in the k-loop (checked in the ISA listing) — tolerated up to 8
-    hot.append((mangled("conv_igemm_s3_kernel", "t", 256, 128, False, True, True, False), 2, 73728, 8))
-    # the parity-class launches of the stride-2 input gradients (round 4: seven per step) take conv_igemm_kernel's extended instantiation
-    hot.append((mangled("conv_igemm_kernel", "t", 128, 128, False, True, True, False), 3, 49152))
-    hot.append((mangled("conv_igemm_kernel", "t", 256, 128, False, True, True, False), 2, 73728))
+            hot.append((mangled("conv_igemm_kernel", dt, 128, 128, False, gen, False, False), 3, 49152))     # 3 workgroups / CU (LDS: 3 x 48 KB)
+            hot.append((mangled("conv_igemm_kernel", dt, 256, 128, False, gen, False, False), 2, 73728))     # 2 workgroups / CU
+            hot.append((mangled("conv_igemm_kernel", dt, 64, 128, False, gen, False, False), 3, 36864))
+        # the parity-class launches of the stride-2 input gradients (seven per step) take conv_igemm_kernel's extended instantiation
+        hot.append((mangled("conv_igemm_kernel", dt, 128, 128, False, True, True, False), 3, 49152))
+        hot.append((mangled("conv_igemm_kernel", dt, 256, 128, False, True, True, False), 2, 73728))
+        if dt == "f":
+            continue                                                  # the shared-tile 3x3 kernel, f32 outputs and the LDS-DMA weight gradient are 16-bit paths
+        for gen in (False, True):
+            hot.append((mangled("conv_igemm_s3_kernel", dt, 128, 128, False, gen, False, False), 3, 49152))
+            hot.append((mangled("conv_igemm_s3_kernel", dt, 256, 128, False, gen, False, False), 2, 73728))
+            hot.append((mangled("conv_igemm_s3_kernel", dt, 64, 128, False, gen, False, False), 3, 36864))
+        # conv2 through the virtual concatenation (extended epilogue; the largest launch of cfg3 and cfg5)
+        hot.append((mangled("conv_igemm_s3_kernel", dt, 256, 128, False, True, True, False), 2, 73728))
+        # f32 heads of the 16-bit network (convfin*, the detection outputs)
+        hot.append((mangled("conv_igemm_kernel", dt, 128, 128, True, True, False, False), 3, 49152))
+        hot.append((mangled("conv_igemm_s3_kernel", dt, 128, 128, True, True, False, False), 3, 49152))
     for tm, tn, lds in ((128, 128, 49152), (128, 64, 36864), (64, 128, 36864), (64, 64, 24576)):
-        hot.append((mangled("conv_wgrad_dma_kernel", tm, tn), 3, lds))
-        hot.append((mangled("conv_wgrad_dma_lin_kernel", tm, tn), 3, lds))      # the instantiation nearly every launch of the step takes (round 4)
+        for suffix in ("", "_f16"):
+            hot.append((mangled("conv_wgrad_dma%s_kernel" % suffix, tm, tn), 3, lds))
+            hot.append((mangled("conv_wgrad_dma_lin%s_kernel" % suffix, tm, tn), 3, lds))      # the instantiation nearly every launch of the step takes
     hot.append((mangled("conv_wgrad_dma_seg_kernel", 128, 128), 3, 49152))
-    for k, w in (("bn_act_kernel", 8), ("bn_act_acc_kernel", 8), ("bn_bwd_apply_kernel", 5), ("relu_bwd_kernel", 8), ("maxpool_fwd_kernel", 4)):
-        hot.append((mangled(k, "t"), w, None))
+    hot.append((mangled("conv_wgrad_dma_seg_f16_kernel", 128, 128), 3, 49152))
+    for dt in DTYPES:
+        for k, w in (("bn_act_kernel", 8), ("bn_bwd_apply_kernel", 5), ("relu_bwd_kernel", 8), ("maxpool_fwd_kernel", 4)):
+            hot.append((mangled(k, dt), w, None))
     return hot
+
+
+# Kernels allowed to keep spilled registers, with the reason; each must still have NO scratch instruction between its first and last
+# MFMA (tools/codeobj.py: scratch_vs_mfma) — a spill parked and fetched outside the k-loop costs a few hundred cycles per workgroup,
+# one inside multiplies by the k-steps (round 5 found the 256-row extended shared-tile kernel reloading gather state — behind a
+# vmcnt(0) that drained its DMA ring — once per tap group; fixed by keeping one fragment offset per tap shift instead of one per fragment).
+def _tolerated():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from codeobj import mangled
+    tol = {}
+    # the general f32 epilogue (cfg2's short-K 1x1 / lateral launches): 10 VGPRs parked across its grouped epilogue loads
+    tol[mangled("conv_igemm_kernel", "f", 128, 128, False, True, False, False)] = 12
+    for dt in ("t", "DF16_"):
+        # f32 heads of the 16-bit network: 8 VGPRs, epilogue only
+        tol[mangled("conv_igemm_kernel", dt, 128, 128, True, True, False, False)] = 12
+        tol[mangled("conv_igemm_s3_kernel", dt, 128, 128, True, True, False, False)] = 12
+        # conv2 through the virtual concatenation: 2 VGPRs + scalar spills in prologue / epilogue
+        tol[mangled("conv_igemm_s3_kernel", dt, 256, 128, False, True, True, False)] = 4
+        # scalar spills only (to VGPR lanes); the 128-row one reserves 20 bytes of scratch it never touches with a scratch instruction
+        tol[mangled("conv_igemm_s3_kernel", dt, 128, 128, False, True, True, False)] = 0
+        tol[mangled("conv_igemm_s3_kernel", dt, 64, 128, False, True, True, False)] = 0
+        tol[mangled("conv_igemm_s3_kernel", dt, 256, 128, False, True, False, False)] = 0
+        tol[mangled("conv_igemm_s3_kernel", dt, 256, 128, True, True, False, False)] = 0
+    return tol
 
 
 def test_hot_kernels_have_no_scratch_and_keep_their_occupancy_class():
     """Round 3 lost 3.3 ms/step to 62 - 112 spilled VGPRs in the 128-row conv tiles before anyone noticed (three epilogue features
     had been compiled into one kernel).  This gate reads the code objects of the BUILT library (tools/codeobj.py: the
-    NT_AMDGPU_METADATA note of every gfx950 ELF in .hip_fatbin) and fails when a kernel the training / inference steps launch
-    by default has a scratch segment, a spilled register, fewer register-limited waves per SIMD than its schedule was tuned for,
-    or another LDS footprint (= another number of workgroups per CU)."""
+    NT_AMDGPU_METADATA note of every gfx950 ELF in .hip_fatbin) and fails when
+      * ANY kernel of the library has a scratch segment or a spilled register and is not on the tolerated list, or exceeds its
+        allowance there, or touches scratch between its first and last MFMA;
+      * a kernel the training / inference steps launch by default — in bf16, f16 or f32 — has fewer register-limited waves per SIMD than
+        its schedule was tuned for, or another LDS footprint (= another number of workgroups per CU)."""
     import sys
     from multiposenet.pytorch_amd import _lib
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -134,21 +177,65 @@ def test_hot_kernels_have_no_scratch_and_keep_their_occupancy_class():
     ks = codeobj.kernels(_lib.LIB_PATH)
     assert len(ks) > 100
     bad = []
+    tol = _tolerated()
+    for k in ks:
+        if not (k["scratch"] or k["spill_v"] or k["spill_s"]):
+            continue
+        frag = [f for f in tol if f in k["name"]]
+        if not frag:
+            bad.append("%s: scratch %d spill v%d s%d and not on the tolerated list" % (k["name"], k["scratch"], k["spill_v"], k["spill_s"]))
+            continue
+        if k["spill_v"] > tol[frag[0]]:
+            bad.append("%s: %d spilled VGPRs, allowance %d" % (k["name"], k["spill_v"], tol[frag[0]]))
+        first, last, sc = codeobj.scratch_vs_mfma(_lib.LIB_PATH, k["name"])
+        inside = [i for i in sc if first <= i <= last]
+        if inside:
+            bad.append("%s: %d scratch instructions inside the MFMA loop (instructions %d..%d): %s" % (k["name"], len(inside), first, last, inside[:8]))
+    for frag in tol:
+        assert any(frag in k["name"] for k in ks), "tolerated entry %s matches no kernel (renamed? update the list)" % frag
     for entry in _hot_kernels():
         frag, min_waves, lds = entry[:3]
-        spill_ok = entry[3] if len(entry) > 3 else 0
         hits = [k for k in ks if frag in k["name"]]
         assert hits, "no kernel matches %s in %s (renamed? update the gate)" % (frag, _lib.LIB_PATH)
         for k in hits:
             waves = codeobj.waves_per_simd(k["vgpr"] + k["agpr"])
-            spilled = k["spill_v"] > spill_ok or (spill_ok == 0 and (k["scratch"] or k["spill_s"]))
-            if spilled or waves < min_waves or (lds is not None and k["lds"] != lds):
-                bad.append("%s: vgpr %d scratch %d spill v%d s%d waves/SIMD %d (want >= %d) lds %d (want %s)"
-                           % (k["name"], k["vgpr"], k["scratch"], k["spill_v"], k["spill_s"], waves, min_waves, k["lds"], lds))
-    assert not bad, "hot kernels lost their register / LDS budget:\n" + "\n".join(bad)
+            if waves < min_waves or (lds is not None and k["lds"] != lds):
+                bad.append("%s: vgpr %d waves/SIMD %d (want >= %d) lds %d (want %s)" % (k["name"], k["vgpr"], waves, min_waves, k["lds"], lds))
+    assert not bad, "kernels lost their register / LDS budget:\n" + "\n".join(bad)
     # nothing in the library may use a stack (dynamic or fixed scratch beyond spills would mean recursion / big local arrays)
     stacky = [k["name"] for k in ks if k["scratch"] > 1024]
     assert not stacky, "kernels with > 1 KB of scratch per lane: %s" % stacky
+
+
+def test_production_library_carries_no_experiment_code_and_few_knobs():
+    """the shipped library must not carry what lost.  (i) no PROF instantiation (s_memtime phase profiles of the
+    three DMA kernels: experiments build only, csrc/Makefile `experiments`), no atomic-statistics kernel; (ii) the C sources read the
+    environment only through mpn_tune(), which is a constant in the production build; (iii) the package + bench.py read at most 25
+    MPN_* environment variables (39 at the end of round 4)."""
+    import re
+    import sys
+    from multiposenet.pytorch_amd import _lib
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import codeobj
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    names = [k["name"] for k in codeobj.kernels(_lib.LIB_PATH)]
+    prof = [n for n in names if "prof_kernel" in n or re.search(r"conv_igemm(_s3)?_kernelI\w+Lb1EEEv13MpnConvParamsi$", n)]
+    assert not prof, "PROF instantiations in the production library: %s" % prof
+    assert not [n for n in names if "bn_act_acc" in n]
+    csrc = os.path.join(ROOT, "multiposenet", "pytorch_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            txt = open(os.path.join(csrc, f)).read()
+            n_env = len(re.findall(r"\bgetenv\s*\(", txt))
+            assert n_env == (1 if f == "common.h" else 0), "%s calls getenv %d times (only mpn_tune in common.h may)" % (f, n_env)
+    knobs = set()
+    for dp, _, fs in os.walk(os.path.join(ROOT, "multiposenet")):
+        for f in fs:
+            if f.endswith(".py"):
+                knobs.update(re.findall(r"environ(?:\.get\(|\[|\.setdefault\()\s*[\"'](MPN_[A-Z0-9_]+)", open(os.path.join(dp, f)).read()))
+    knobs.update(re.findall(r"environ(?:\.get\(|\[|\.setdefault\()\s*[\"'](MPN_[A-Z0-9_]+)", open(os.path.join(ROOT, "bench.py")).read()))
+    assert len(knobs) <= 25, "%d MPN_* environment knobs: %s" % (len(knobs), sorted(knobs))
 
 
 def test_stride2_dgrad_class_plan_covers_every_pixel_and_every_live_tap_once():

@@ -18,127 +18,6 @@ def _need_gpu():
     _lib.lib()
 
 
-def _acc_alloc(C):
-    acc = torch.zeros((C, 2), dtype=torch.int64, device="cuda")
-    return acc, (lambda tiles, c: acc)
-
-
-# ------------------------------------------------------------------------------------------------ atomic statistics
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", [(2, 30, 30, 64, 256, 1), (3, 17, 19, 128, 128, 3), (1, 40, 40, 256, 1024, 1), (2, 8, 8, 64, 64, 3), (8, 120, 120, 64, 64, 1)])
-def test_conv_atomic_statistics_equal_the_tile_table(dtype, case):
-    """fpn.py:28-34 in training mode.  The conv epilogue adds (sum, sum^2) of its tile to one pair of 64-bit fixed-point accumulators
-    per channel (mpn.h: stats_atomic) instead of writing a [tiles][C][2] table: the totals must equal the table's column sums to the
-    fixed-point resolution (2^-28 / 2^-20 per tile, rounded to nearest), be bit-identical from run to run (integer adds commute),
-    and leave the output tensor untouched (the 900-tile case has every XCD adding to the same words)."""
-    from multiposenet.pytorch_amd import ops
-    B, H, W, Cin, Cout, k = case
-    x = rnd(dtype, rng_normal(11, B, Cin, H, W))
-    w = rnd(dtype, rng_normal(12, Cout, Cin, k, k) / float(np.sqrt(Cin * k * k)))
-    y0, table = ops.conv_forward(to_act(x, dtype), w_krsc(w, dtype), Cout, k, k, 1, k // 2, want_stats=True)
-    tiles = table.shape[0]
-    runs = []
-    for _ in range(3):
-        acc, alloc = _acc_alloc(Cout)
-        y1, sa = ops.conv_forward(to_act(x, dtype), w_krsc(w, dtype), Cout, k, k, 1, k // 2, want_stats=True, stat_acc=alloc)
-        assert isinstance(sa, ops.StatAcc) and sa.count == B * H * W
-        torch.cuda.synchronize()
-        assert torch.equal(y1.t, y0.t), "the statistics mode changed the convolution output"
-        runs.append(acc.clone())
-    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), "atomic statistics differ from run to run"
-    tot = table.double().sum(0).cpu()
-    got1 = runs[0][:, 0].double().cpu() / 2.0 ** 28
-    got2 = runs[0][:, 1].double().cpu() / 2.0 ** 20
-    e1 = float((got1 - tot[:, 0]).abs().max()); e2 = float((got2 - tot[:, 1]).abs().max())
-    report("atomic stats %s %s: tiles %d  |sum err| %.3e (lim %.3e)  |sumsq err| %.3e (lim %.3e)" % (case, dtype, tiles, e1, tiles * 2.0 ** -29, e2, tiles * 2.0 ** -21))
-    assert e1 <= tiles * 2.0 ** -29 + 1e-12 and e2 <= tiles * 2.0 ** -21 + 1e-12
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("C", [64, 256, 1024, 2048])
-def test_bn_act_from_atomic_statistics_equals_finalize_plus_bn_act(dtype, C):
-    """mpn_bn_act_acc_forward == mpn_bn_finalize_train + mpn_bn_act_forward (coefficients, running statistics, z, mask bits), and
-    both == torch's F.batch_norm in training mode within the kernel tolerances of test_batchnorm_train_and_eval."""
-    from multiposenet.pytorch_amd import ops
-    B, H, W = 2, 21, 13
-    P = B * H * W
-    y = rnd(dtype, rng_normal(41, B, C, H, W) * 1.5 + 0.3)
-    res = rnd(dtype, rng_normal(42, B, C, H, W))
-    gamma = torch.rand(C, generator=torch.Generator().manual_seed(43)) + 0.5
-    beta = rng_normal(44, C) * 0.1
-    rm0, rv0 = rng_normal(45, C) * 0.1, torch.rand(C, generator=torch.Generator().manual_seed(46)) + 0.5
-    ya = to_act(y, dtype)
-    yv = from_act(ya).double()
-    s1, s2 = yv.sum((0, 2, 3)), (yv * yv).sum((0, 2, 3))
-    table = torch.stack([s1, s2], 1).float().unsqueeze(0).contiguous().cuda()
-    acc = torch.stack([torch.round(table[0, :, 0].double() * 2.0 ** 28), torch.round(table[0, :, 1].double() * 2.0 ** 20)], 1).to(torch.int64).contiguous()
-    for relu, use_res in ((True, False), (True, True), (False, False)):
-        rm, rv = rm0.clone(), rv0.clone()
-        z = F.batch_norm(y.clone(), rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5)
-        if use_res:
-            z = z + res
-        if relu:
-            z = F.relu(z)
-        ra = to_act(res, dtype) if use_res else None
-        rmA, rvA = rm0.clone().cuda(), rv0.clone().cuda()
-        stA = ops.bn_finalize_train(table, P, gamma.cuda(), beta.cuda(), rmA, rvA)
-        zA = ops.bn_act(ya, stA, relu, res=ra, want_mask=relu)
-        rmB, rvB = rm0.clone().cuda(), rv0.clone().cuda()
-        zB, stB = ops.bn_act_acc(ya, ops.StatAcc(acc, P), gamma.cuda(), beta.cuda(), rmB, rvB, 0.1, 1e-5, relu, res=ra, want_mask=relu)
-        torch.cuda.synchronize()
-        for name, a, b in (("mean", stA.mean, stB.mean), ("invstd", stA.invstd, stB.invstd), ("scale", stA.scale, stB.scale),
-                           ("shift", stA.shift, stB.shift), ("running_mean", rmA, rmB), ("running_var", rvA, rvB)):
-            err = float((a - b).abs().max()); lim = 2e-6 * max(float(a.abs().max()), 1e-3)
-            assert err <= lim, "%s: atomic path differs from the finalize launch by %.3e (> %.3e)" % (name, err, lim)
-        check_close("bn_act_acc fwd C=%d relu=%s res=%s %s" % (C, relu, use_res, dtype), from_act(zB), z, dtype)
-        check_close("bn_act_acc vs bn_act", from_act(zB), from_act(zA), dtype, factor=0.02)
-        check_close("bn_act_acc running_mean", rmB.cpu(), rm, torch.float32)
-        check_close("bn_act_acc running_var", rvB.cpu(), rv, torch.float32)
-        if relu:
-            diff = int((zA.mask != zB.mask).sum())
-            assert diff <= zA.mask.numel() // 1000, "mask bits differ in %d of %d bytes" % (diff, zA.mask.numel())
-
-
-def test_training_step_with_atomic_statistics_matches_the_finalize_launches_and_is_reproducible():
-    """Whole network (R50 train_both... keypoint + detection losses, batch-statistics BatchNorm, fp32): with the atomic statistics on,
-    loss, heat-maps, running statistics and every parameter gradient equal those of the finalize-launch path within fp32 rounding
-    noise, and two runs of the atomic path are bit-identical (integer atomics commute; the reference's own cuDNN statistics are not)."""
-    from test_model_gpu import get_model, t
-    from multiposenet.pytorch_amd.network.posenet import poseNet
-    from multiposenet.pytorch_amd import synthetic as weightgen
-    B, S = 2, 128
-    img = t(weightgen.gen_images(410, B, S, S)).cuda()
-    heat, wgt = (t(a).cuda() for a in weightgen.gen_keypoint_gt(411, B, S // 4, S // 4))
-    out = {}
-    for mode in ("0", "1", "1"):
-        m = get_model(50, torch.float32)
-        eng = m._engine
-        default = (eng.bn_atomic, eng.bn_atomic_min_tiles, eng.bn_atomic_max_tiles)
-        eng.bn_atomic, eng.bn_atomic_min_tiles, eng.bn_atomic_max_tiles = mode == "1", 0, 1 << 30      # every BatchNorm layer, whatever its size
-        for p in m.prn.parameters():
-            p.requires_grad = False
-        m.train()
-        m._arena.ensure_grads()
-        m._arena.grad_flat.zero_()
-        pred, saved = m([img, "keypoint_subnet"])
-        loss, _ = poseNet.build_loss(saved, "keypoint_subnet", heat, wgt)
-        loss.backward()
-        torch.cuda.synchronize()
-        eng.bn_atomic, eng.bn_atomic_min_tiles, eng.bn_atomic_max_tiles = default
-        rs = torch.cat([v.flatten().float() for k, v in sorted(m.state_dict().items()) if "running_" in k])
-        out.setdefault(mode, []).append((pred.detach().clone(), float(loss), m._arena.grad_flat.clone(), rs.clone()))
-    (p0, l0, g0, r0), = out["0"]
-    (p1, l1, g1, r1), (p2, l2, g2, r2) = out["1"]
-    assert torch.equal(p1, p2) and l1 == l2 and torch.equal(g1, g2) and torch.equal(r1, r2), "atomic-statistics step is not bit-reproducible"
-    rel = abs(l1 - l0) / abs(l0)
-    perr = float((p1 - p0).abs().max())
-    gerr = float((g1 - g0).norm() / g0.norm())
-    rerr = float((r1 - r0).abs().max())
-    report("atomic BN statistics vs finalize launches (R50 kp 128x128 B=2 fp32): loss rel %.2e, heat-map abs %.2e, grad rel-L2 %.2e, running stats abs %.2e"
-           % (rel, perr, gerr, rerr))
-    assert rel <= 1e-5 and perr <= 1e-4 and gerr <= 1e-3 and rerr <= 1e-5
-
-
 # ------------------------------------------------------------------------------------------------ TTA driver vs the real Tester
 def test_tta_driver_matches_the_real_reference_tester(tmp_path):
     """evaluate/tester.py:131-193,256-331.  tests/golden/make_golden_tta.py drove the REAL reference ``Tester`` (coco_eval,
@@ -245,6 +124,11 @@ def test_bench_spawn_path_runs_two_ranks_to_one_json_line():
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["not_a_measurement"] is True
     assert out["config"]["global_batch"] == 8 and out["config"]["parallelism"].startswith("dp2")
     assert "cpu_baseline" not in out and out["value"] > 0 and out["scaling"] == "weak"
+    # round 5: the line describes the process group it ran on (what the first 8-GPU line will be read for)
+    d = out["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and d["rccl_version"] is None
+    assert d["buckets"] >= 1 and d["collectives_per_step"] == d["buckets"] and d["bucket_mb"] == 32.0 and d["gradient_bytes_per_step"] > 1e6
+    assert len(d["per_rank_ms"]) == 2 and all(v > 0 for v in d["per_rank_ms"]) and len(d["allreduce_ms_exposed"]) == 2
     report("bench.py --gpus 2 --shared-device-test: spawn -> rendezvous -> 3 data-parallel steps -> one JSON line (%.1f img/s on one shared device, not a measurement)"
            % out["value"])
 

@@ -52,6 +52,13 @@ def kernels(so_path, arch="gfx950"):
     """One dict per kernel: name (mangled), vgpr, agpr, sgpr, scratch, spill_v, spill_s, lds, max_threads."""
     out = []
     for elf in code_objects(so_path, arch):
+        out.extend(_kernels_of(elf))
+    return out
+
+
+def _kernels_of(elf):
+    out = []
+    if True:
         for _name, typ, off, size in _sections(elf):
             if typ != 7:                     # SHT_NOTE
                 continue
@@ -71,6 +78,28 @@ def kernels(so_path, arch="gfx950"):
                                     "spill_v": k.get(".vgpr_spill_count", 0), "spill_s": k.get(".sgpr_spill_count", 0),
                                     "lds": k.get(".group_segment_fixed_size", 0), "max_threads": k.get(".max_flat_workgroup_size", 0)})
     return out
+
+
+def scratch_vs_mfma(so_path, name_fragment, arch="gfx950", objdump="/opt/rocm/lib/llvm/bin/llvm-objdump"):
+    """Where a kernel's scratch traffic sits relative to its MFMA loop: disassembles the (first) kernel whose mangled name contains
+    `name_fragment` and returns (instruction index of the first v_mfma, of the last v_mfma, [indices of scratch_* instructions]).
+    A spill that is stored and reloaded outside [first, last] costs a few hundred cycles per workgroup; one inside multiplies by the
+    k-steps (round 3 lost 3.3 ms/step that way).  tests/test_round4_cpu.py uses this for the kernels it tolerates spills in."""
+    import subprocess
+    import tempfile
+    for elf in code_objects(so_path, arch):
+        names = [k["name"] for k in _kernels_of(elf)]
+        hit = [n for n in names if name_fragment in n]
+        if not hit:
+            continue
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(elf); f.flush()
+            txt = subprocess.check_output([objdump, "-d", "--disassemble-symbols=" + hit[0], f.name]).decode()
+        ins = [l.split("//")[0].strip() for l in txt.splitlines() if l.startswith("\t")]
+        mf = [i for i, l in enumerate(ins) if l.startswith("v_mfma")]
+        sc = [i for i, l in enumerate(ins) if l.startswith("scratch_")]
+        return (mf[0] if mf else -1), (mf[-1] if mf else -1), sc
+    raise KeyError(name_fragment)
 
 
 def waves_per_simd(vgpr_plus_agpr):

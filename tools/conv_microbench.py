@@ -9,6 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from multiposenet.pytorch_amd import ops
+from multiposenet.pytorch_amd import _lib as _mpn_lib
+_mpn_lib.use_experiments_build()      # ablation bits / PROF instantiations live in the experiments build (csrc/Makefile)
 
 SHAPES_ALL = [
     # name, B, H, W, Cin, Cout, k, stride, pad, stats

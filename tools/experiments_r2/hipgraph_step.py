@@ -1,4 +1,7 @@
-"""The training step as ONE hipGraph launch.
+"""REJECTED PATH, kept out of the package as the record (round 2: a captured hipGraph replays node by node from the host on this
+stack and is slower than the recorded launch list, multiposenet/pytorch_amd/replay.py).  Was multiposenet/pytorch_amd/graph.py through round 4.
+
+The training step as ONE hipGraph launch.
 
 The reference's step (training/trainer.py:245-259: forward, build_loss, zero_grad, backward, step) costs the
 host ~2 000 kernel launches here (the Python tape of engine.py); enqueueing them takes about as long as the
@@ -28,8 +31,10 @@ from collections import OrderedDict
 
 import torch
 
-from . import ops
-from .network import losses
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from multiposenet.pytorch_amd import ops
+from multiposenet.pytorch_amd.network import losses
 
 _epoch = itertools.count(1)
 
@@ -45,7 +50,7 @@ class GraphedTrainStep(object):
         self.eager_steps = max(1, int(eager_steps))
         # layers of weight-gradient work handed to the side stream per fork point inside the captured graph (every
         # cross-stream edge of a hipGraph costs a barrier packet and a cache write-back at replay)
-        self.fork_every = int(fork_every if fork_every is not None else os.environ.get("MPN_GRAPH_FORK_EVERY", "8"))
+        self.fork_every = int(fork_every if fork_every is not None else os.environ.get("HIPGRAPH_FORK_EVERY", "8"))
         self._entries = {}
         self._seen = {}
         self.replays = 0

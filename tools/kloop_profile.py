@@ -17,6 +17,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 from multiposenet.pytorch_amd import ops
+from multiposenet.pytorch_amd import _lib as _mpn_lib
+_mpn_lib.use_experiments_build()      # ablation bits / PROF instantiations live in the experiments build (csrc/Makefile)
 from multiposenet.pytorch_amd._lib import call
 
 dt, dev = torch.bfloat16, "cuda"
