@@ -140,33 +140,38 @@ def prn_process_batch(model, kps_list, bbox_lists, file_names=None, image_ids=No
     w, h = int(18 * coeff), int(28 * coeff)
     if (h, w) != (56, 36):
         raise MpnError("the reference reshapes the PRN output to (56, 36, 17) (tester.py:404): coeff must be 2")
-    peaks_all = [_peaks_by_joint(k) for k in kps_list]
     boxes_all = [[[b[0], b[1], b[2] - b[0], b[3] - b[1]] for b in bl] for bl in bbox_lists]        # tester.py:355-357
     results = [[] for _ in range(nimg)]
-    flat_peaks, joint_off, flat_boxes, box_start = [], [], [], [0]
+    # tester.py:337-349 without a Python loop per peak (round 5): per image one list -> array conversion, the joint types grouped by a
+    # STABLE sort (the reference's per-type scans keep the input order inside a type), offsets by bincount
+    flat_peaks, joint_off, box_start = [], np.zeros((nimg, 18), dtype=np.int64), [0]
+    base = 0
     for i in range(nimg):
-        offs = []
-        for j in range(17):
-            offs.append(len(flat_peaks))
-            flat_peaks += [(p[0], p[1]) for p in peaks_all[i][j]]
-        offs.append(len(flat_peaks))
-        joint_off.append(offs)
-        flat_boxes += boxes_all[i]
-        box_start.append(len(flat_boxes))
-    if not flat_boxes:
+        a = np.asarray(kps_list[i], dtype=np.float64)
+        a = a.reshape(-1, a.shape[-1]) if a.size else np.zeros((0, 5))
+        jt = a[:, -1]
+        a = a[(jt == np.floor(jt)) & (jt >= 0) & (jt < 17)]
+        jt = a[:, -1].astype(np.int64)
+        flat_peaks.append(a[np.argsort(jt, kind="stable"), :2])
+        joint_off[i, 0] = base
+        joint_off[i, 1:] = base + np.cumsum(np.bincount(jt, minlength=17))
+        base = int(joint_off[i, 17])
+        box_start.append(box_start[-1] + len(boxes_all[i]))
+    if box_start[-1] == 0:
         return results                                     # tester.py:359-360
-    bk = prn_assign_arrays(model, np.asarray(flat_peaks, dtype=np.float64).reshape(-1, 2), np.asarray(joint_off, dtype=np.int32),
+    flat_boxes = [b for bl in boxes_all for b in bl]
+    bk = prn_assign_arrays(model, np.concatenate(flat_peaks, 0) if flat_peaks else np.zeros((0, 2)), joint_off.astype(np.int32),
                            np.asarray(flat_boxes, dtype=np.float64).reshape(-1, 4), np.asarray(box_start, dtype=np.int32), in_thres, fast)
+    # tester.py:487-511; the pose score is the reference's left-to-right float sum over the 17 joints
+    kp51 = bk.reshape(bk.shape[0], 51).tolist()
     for i in range(nimg):
-        for bi in range(box_start[i], box_start[i + 1]):     # tester.py:487-511
-            k = np.zeros(51)
-            k[0::3], k[1::3], k[2::3] = bk[bi, :, 0], bk[bi, :, 1], bk[bi, :, 2]
+        for bi in range(box_start[i], box_start[i + 1]):
             pose_score = 0
             for f in range(17):
                 pose_score += bk[bi, f, 2]
             pose_score /= 17.0
             results[i].append({'image_id': image_ids[i], 'file_name': file_names[i], 'category_id': 1, 'bbox': boxes_all[i][bi - box_start[i]],
-                               'score': pose_score, 'keypoints': k.tolist()})
+                               'score': pose_score, 'keypoints': kp51[bi]})
     return results
 
 

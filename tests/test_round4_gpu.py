@@ -480,7 +480,13 @@ def test_training_step_with_parity_class_dgrads_equals_the_gather_step(mode):
     assert torch.equal(l0, l1)
     rel = float((g0 - g1).norm() / g0.norm())
     report("training step, stride-2 dgrads by parity classes vs gather (%s): gradient arena rel-L2 %.2e" % (mode, rel))
-    assert rel <= 1e-2
+    # THE GATE for the parity-class launches is per kernel: test_stride2_input_gradient_by_parity_classes_matches_torch_and_the_gather
+    # (torch autograd, <= 3e-5 against the gather form) and the teacher-forced rounding-oracle tests.  This whole-step comparison is a
+    # self-comparison of two summation orders: with frozen statistics it is tight (measured 8e-5) and asserted; with batch statistics
+    # the bf16 backward amplifies a re-ordered sum chaotically through 33 BatchNorm layers (measured 8.9e-3 — 11 % under a 1e-2 limit
+    # that the next harmless re-ordering would trip): reported, and bounded only against a real defect (a wrong
+    # tap or class shows up as >= 3e-1)
+    assert rel <= (1e-3 if mode == "frozen_affine" else 1e-1)
 
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 128), (2, 15, 13, 128, 256), (1, 60, 60, 256, 512)])

@@ -91,8 +91,30 @@ def main():
         ok = (b4[:, 2] >= 1) & (b4[:, 3] >= 1)
         start = np.concatenate([[0], np.cumsum(np.add.reduceat(ok, np.concatenate([[0], np.cumsum(nb)[:-1]])) if ok.size else nb * 0)]).astype(np.int32)
         return prn_assign_arrays(m, peaks_xy, joint_off, b4[ok], start)
+    def full_lists():
+        """The SAME workload as full_arrays() through the reference's list interface (tester.py:158-168: joint rows as a list of lists,
+        boxes as a list per image -> prn_process_batch -> result dicts): what the interface itself costs."""
+        with torch.no_grad():
+            heat, boxes, scores, kept = m.forward_all_images_padded(img)
+        pk, cnt = NMS_batch_arrays({'thre1': thre1}, heat, 4.0)
+        b4 = boxes[:, :, :4].double().cpu().numpy() if boxes.dim() == 3 else boxes.double().cpu().numpy()
+        kps, bl = [], []
+        for b in range(args.batch):
+            rows = []
+            for j in range(pk.shape[1]):
+                if j == 1:
+                    continue                                               # the neck is dropped, later types shift down (tester.py:161-165)
+                n = min(int(cnt[b, j]), args.people)
+                if n:
+                    rows.append(np.concatenate([pk[b, j, :n], np.full((n, 1), float(max(0, j - 1)))], 1))
+            kps.append(np.concatenate(rows, 0).tolist() if rows else [])
+            bb = b4[b, :min(int(kept[b]), args.people)]
+            bl.append([r for r in bb.tolist() if r[2] - r[0] >= 1 and r[3] - r[1] >= 1])
+        return prn_process_batch(m, kps, bl)
     for name, fn in (("network only (backbone, both pyramids, both heads)", net_only), ("network + decode + NMS for every image", net),
                      ("+ heat-map peaks + PRN assignment, reference list interface, threshold 0.1 (noise: hundreds of peaks per plane)", full),
+                     ("+ heat-map peaks + PRN assignment (%d people / image; the SAME workload as the next line through the reference's list interface: "
+                      "joint rows / boxes as Python lists in, result dicts out)" % args.people, full_lists),
                      ("+ heat-map peaks + PRN assignment (%d people / image; flat arrays, compact candidates, C++ matching)" % args.people, full_arrays)):
         fn()
         torch.cuda.synchronize()
