@@ -997,7 +997,9 @@ inline int pick_tc(const MpnConvParams& p, long tilesP) {
     static const long min_blocks256 = mpn_tune("MPN_TC256_MIN_BLOCKS", 400);
     static const long min_ksteps256 = mpn_tune("MPN_TC256_MIN_KSTEPS", 16);
     const long ksteps = (long)p.R * p.S * p.Cin / (p.dtype == MPN_F32 ? 16 : 32);
-    if (cout_store >= 256 && tilesP * ((cout_store + 255) / 256) >= min_blocks256 && ksteps >= min_ksteps256) return 256;
+    // (f32: the exact-fp32 MFMA needs 8 passes per 16x16x4 — the loop is bound by the matrix pipe, not by operand delivery, and three
+    //  128-row workgroups per CU keep it busier than two 256-row ones: cfg2 55.7 -> 54.7 ms, profiles/r05_cfg2_tile_rule_sweep.txt)
+    if (p.dtype != MPN_F32 && cout_store >= 256 && tilesP * ((cout_store + 255) / 256) >= min_blocks256 && ksteps >= min_ksteps256) return 256;
     const long blocks128 = tilesP * ((cout_store + 127) / 128);
     return blocks128 >= min_blocks ? 128 : 64;
 }

@@ -845,7 +845,9 @@ extern "C" int mpn_conv_wgrad_chunks(const MpnWgradParams* p) {
     wgrad_tiles(*p, tm, tn);
     const long tiles = (long)((p->Cin + tm - 1) / tm) * ((p->Cout + tn - 1) / tn) * p->R * p->S;
     const long P = wgrad_total_pixels(*p);
-    static const long target = mpn_tune("MPN_WGRAD_TARGET", kWgradTarget);
+    static const long target16 = mpn_tune("MPN_WGRAD_TARGET", kWgradTarget);
+    // f32 (register-staged parity kernel, matrix-pipe bound): three workgroups per CU's worth of slices (cfg2 55.7 -> 55.1 ms; 256: 62.3)
+    const long target = (p->dtype == MPN_F32 && target16 == kWgradTarget) ? 768 : target16;
     static const long minpix = mpn_tune("MPN_WGRAD_MINPIX", 512);
     // ~2 workgroups per CU (long slices run near peak, partial-sum traffic dominates beyond) and NEVER one more than that: rounding the
     // slice count up put 540 workgroups on the 512 slots of the 3x3 256-channel layers — the 28 that share a CU three ways finish last,

@@ -35,6 +35,27 @@ def main():
         print("\n# %s by launch geometry (workgroups)" % short(kn))
         for r in g[:12]:
             print("  blocks=%7d calls/step=%6.1f  ms/step=%8.3f  avg=%9.1f us" % (r[0], r[1] / steps, r[2] / steps, r[3]))
+    foreign_kernels_per_step(cur)
+
+
+def foreign_kernels_per_step(cur):
+    """Per optimizer-step window (adam kernel to adam kernel): launches that are NOT this library's — hipMemcpy kernels
+    (__amd_rocclr_copyBuffer / fillBuffer) and torch element-wise kernels — so that set-up steps (eager pass + recording, which do run
+    torch ops) can be told from replayed steps."""
+    rows = cur.execute("select start, end, name from kernels order by start").fetchall()
+    adam = [r for r in rows if "adam" in r[2]]
+    if len(adam) < 3:
+        return
+    print("\n# launches per step window that are not libmpn_hip kernels (copyBuffer / fillBuffer / at::native): window index -> count, kernel time us")
+    wins = [(rows[0][0], adam[0][0])] + [(a[1], b[0]) for a, b in zip(adam[:-1], adam[1:])]
+    out = []
+    for i, (lo, hi) in enumerate(wins):
+        f = [r for r in rows if lo <= r[0] and r[1] <= hi and ("rocclr" in r[2] or "at::native" in r[2] or "elementwise" in r[2])]
+        out.append((i, len(f), sum(r[1] - r[0] for r in f) / 1e3))
+    print("  " + "  ".join("%d:%d(%.0fus)" % o for o in out))
+    body = sorted(o[1] for o in out[3:])
+    if body:
+        print("  steady state (windows 3..): min %d median %d max %d launches per step" % (body[0], body[len(body) // 2], body[-1]))
 
 
 if __name__ == "__main__":
