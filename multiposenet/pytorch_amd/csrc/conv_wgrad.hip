@@ -35,6 +35,7 @@ template <> __device__ __forceinline__ f32x4_t mma16<float>(const u32x4_t&, cons
 template <typename T> struct Ones16;
 template <> struct Ones16<bf16_t> { static constexpr unsigned kPair = 0x3F803F80u; };
 template <> struct Ones16<f16_t> { static constexpr unsigned kPair = 0x3C003C00u; };
+template <> struct Ones16<float> { static constexpr unsigned kPair = 0u; };        // unused: the f32 bias sum multiplies by a scalar 1.0f
 
 struct PixState {      // incremental (b, ho, wo) walker over the dense output-pixel index
     int b, ho, wo;
@@ -336,6 +337,15 @@ template <int ROWB> __device__ __forceinline__ int dma_swz(int k) {
     return ROWB >= 256 ? 2 * ((k & 3) | (((k >> 3) & 1) << 2)) : 2 * (((k >> 1) & 1) | (((k >> 3) & 1) << 1));
 }
 
+// f32 tiles (round 5): the exact-fp32 MFMA takes ONE k per lane, so fragments are ds_read_b32 — 16 lanes read 16 consecutive channels
+// (one 64-byte group) of a row, the four 16-lane groups of an instruction read rows k, k+1, k+2, k+3.  Rows are 256 / 512 bytes (a
+// multiple of the 256-byte bank row), so the four rows would meet on the same banks: the 64-byte group index is XORed with k & 3
+// (16-byte chunk units: (k & 3) << 2), which puts the four groups of every instruction on four distinct quarter bank rows.
+template <typename T, int ROWB> __device__ __forceinline__ int dma_swz_t(int k) {
+    if (sizeof(T) == 4) return (k & 3) << 2;
+    return dma_swz<ROWB>(k);
+}
+
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ const void* rfl_ptr(const void* q) {
     const uint64_t a = (uint64_t)q;
@@ -360,14 +370,16 @@ template <typename T, int TM, int TN, bool SEG, bool PROF = false, bool LIN = fa
 __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, long chunk_pixels, unsigned long long* prof = nullptr) {
     const bool ablate_stores = (chunk_pixels >> 62) & 1;     // MPN_WGRAD_ABLATE=2 (tools only): how much do the partial stores cost?
     chunk_pixels &= ~(1L << 62);
-    constexpr int KP = 32, NST = 3;
-    constexpr int ROWA = TM * 2, ROWB = TN * 2;              // bytes per pixel row of each tile
+    constexpr int ES = (int)sizeof(T), EV = 16 / ES;         // element bytes, elements per 16-byte DMA chunk
+    constexpr int KP = 64 / ES, NST = 3;                     // pixels per k-step: 32 (16-bit) / 16 (f32) — 16 KB per stage at 128 x 128 either way
+    constexpr int ROWA = TM * ES, ROWB = TN * ES;            // bytes per pixel row of each tile
     constexpr int A_BYTES = KP * ROWA, B_BYTES = KP * ROWB;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int QA = A_BYTES / 4096, QB = B_BYTES / 4096;  // DMA instructions (1 KiB each) per wave per k-step
     constexpr int RPA = 1024 / ROWA, RPB = 1024 / ROWB;      // tile rows covered by one instruction
     constexpr int MM = TM / 32, MN = TN / 32;                // 16x16 fragments per wave (2 x 2 waves)
     static_assert((TM == 256 || TM == 128 || TM == 64) && (TN == 128 || TN == 64), "tile widths");
+    static_assert(ES == 2 || (TM <= 128 && !SEG), "f32: 64 / 128-wide tiles, single tensor");
     __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -410,13 +422,13 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, lo
     }
 
     const int dr = r - p.pad, dsx = s - p.pad;                       // LIN: tap offset in lines / pixels
-    const long tap_bytes = LIN ? ((long)dr * p.W + dsx) * p.x_sW * 2 : 0;      // base moves by the tap; a valid (ho + dr, wo + dsx) never reads before x
-    long x_bytes_l = (long)p.B * p.x_sB * 2 - tap_bytes;
+    const long tap_bytes = LIN ? ((long)dr * p.W + dsx) * p.x_sW * ES : 0;      // base moves by the tap; a valid (ho + dr, wo + dsx) never reads before x
+    long x_bytes_l = (long)p.B * p.x_sB * ES - tap_bytes;
     if (x_bytes_l < 0) x_bytes_l = 0;
     if (x_bytes_l > 0x7fffffffL) x_bytes_l = 0x7fffffffL;
     const i32x4_t rsrc_x = make_rsrc((const char*)p.x + tap_bytes, (unsigned)x_bytes_l);
     const bool halo = LIN && (p.R > 1 || p.S > 1 || p.pad != 0);     // uniform: 1x1 needs no predicate and no pixel digits
-    const i32x4_t rsrc_dy = make_rsrc(p.dy, (unsigned)((k_end > k_begin ? k_end : 0) * (long)p.dy_sP * 2));
+    const i32x4_t rsrc_dy = make_rsrc(p.dy, (unsigned)((k_end > k_begin ? k_end : 0) * (long)p.dy_sP * ES));
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
 
@@ -426,24 +438,24 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, lo
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
         const int row = ((int)wave_u * QA + q) * RPA + lane / (ROWA / 16);
-        const int chan = ((lane % (ROWA / 16)) ^ dma_swz<ROWA>(row)) * 8;
+        const int chan = ((lane % (ROWA / 16)) ^ dma_swz_t<T, ROWA>(row)) * EV;
         a_chan[q] = m0 + chan;
         a_on[q] = (m0 + chan) < p.Cin;
         long pix = k_begin + row;
         if (LIN) {           // a_chan holds the lane's byte offset from the tap-shifted base (rows past the end run out of the descriptor or meet zero dY rows)
-            a_chan[q] = a_on[q] ? (int)(unsigned)((pix * p.x_sW + m0 + chan) * 2) : (int)DMA_OOB;
+            a_chan[q] = a_on[q] ? (int)(unsigned)((pix * p.x_sW + m0 + chan) * ES) : (int)DMA_OOB;
         } else if (pix >= P) pix = P - 1;     // beyond-the-end rows meet zero dY rows
         a_px[q].init(pix, p.Ho, p.Wo);
     }
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
         const int row = ((int)wave_u * QB + q) * RPB + lane / (ROWB / 16);
-        const int chan = ((lane % (ROWB / 16)) ^ dma_swz<ROWB>(row)) * 8;
-        b_voff[q] = ((n0 + chan) < dy_cs) ? (unsigned)(((k_begin + row) * (long)p.dy_sP + n0 + chan) * 2) : DMA_OOB;
+        const int chan = ((lane % (ROWB / 16)) ^ dma_swz_t<T, ROWB>(row)) * EV;
+        b_voff[q] = ((n0 + chan) < dy_cs) ? (unsigned)(((k_begin + row) * (long)p.dy_sP + n0 + chan) * ES) : DMA_OOB;
     }
-    const unsigned b_step = (unsigned)__builtin_amdgcn_readfirstlane((int)(KP * p.dy_sP * 2));
+    const unsigned b_step = (unsigned)__builtin_amdgcn_readfirstlane((int)(KP * p.dy_sP * ES));
     unsigned b_soff = 0;
-    const unsigned a_step = (unsigned)__builtin_amdgcn_readfirstlane((int)(KP * p.x_sW * 2));
+    const unsigned a_step = (unsigned)__builtin_amdgcn_readfirstlane((int)(KP * p.x_sW * ES));
     unsigned a_soff = 0;
     unsigned a_sel[QA];                  // LIN: the lane's offset or the out-of-range marker for the k-step about to be queued
 #pragma unroll
@@ -472,7 +484,7 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, lo
             const int hi = a_px[q].ho * p.stride - p.pad + r, wi = a_px[q].wo * p.stride - p.pad + s;
             const bool ok = a_on[q] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             const unsigned off = ((unsigned)a_px[q].b * (unsigned)p.x_sB + (unsigned)(hi >> vsh) * (unsigned)p.x_sH +
-                                  (unsigned)(wi >> vsh) * (unsigned)p.x_sW + (unsigned)(a_chan[q] - vc0)) * 2u;
+                                  (unsigned)(wi >> vsh) * (unsigned)p.x_sW + (unsigned)(a_chan[q] - vc0)) * (unsigned)ES;
             lds_dma16(ok ? off : DMA_OOB, rsrc_x, 0u, __builtin_amdgcn_readfirstlane(st + (wave_u * QA + q) * 1024u));
             a_px[q].advance_digits(adv_b, adv_h, adv_w, p.Ho, p.Wo);
         }
@@ -517,10 +529,39 @@ __device__ __forceinline__ void conv_wgrad_dma_body(const MpnWgradParams& pk, lo
     f32x4_t accb[MN];
 #pragma unroll
     for (int j = 0; j < MN; ++j) accb[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const u32x4_t ones = {Ones16<T>::kPair, Ones16<T>::kPair, Ones16<T>::kPair, Ones16<T>::kPair};
     auto compute = [&](unsigned stage) {
         const unsigned char* la = lds + stage * STAGE_BYTES;
         const unsigned char* lb = la + A_BYTES;
+        if constexpr (ES == 4) {
+            // exact-fp32 MFMA (16x16x4, one k per lane): lane -> channel (lane & 15) of a 16-wide block, row kq * 4 + (lane >> 4)
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                const int krow = kq * 4 + (lane >> 4);
+                const int key = (lane >> 4) << 2;                            // == dma_swz_t<float>(krow): krow & 3 == lane >> 4
+                float fa[MM], fb[MN];
+#pragma unroll
+                for (int i = 0; i < MM; ++i) {
+                    const int c = wm * (TM / 2) + i * 16 + (lane & 15);
+                    fa[i] = *reinterpret_cast<const float*>(la + krow * ROWA + (((c >> 2) ^ key) * 16) + (c & 3) * 4);
+                }
+#pragma unroll
+                for (int j = 0; j < MN; ++j) {
+                    const int c = wn * (TN / 2) + j * 16 + (lane & 15);
+                    fb[j] = *reinterpret_cast<const float*>(lb + krow * ROWB + (((c >> 2) ^ key) * 16) + (c & 3) * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < MM; ++i)
+#pragma unroll
+                    for (int j = 0; j < MN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                if (do_bias) {
+#pragma unroll
+                    for (int j = 0; j < MN; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, fb[j], accb[j], 0, 0, 0);
+                }
+            }
+            return;
+        }
+        const u32x4_t ones = {Ones16<T>::kPair, Ones16<T>::kPair, Ones16<T>::kPair, Ones16<T>::kPair};
         u32x4_t fa[MM], fb[MN];
 #pragma unroll
         for (int i = 0; i < MM; ++i) fa[i] = frag(la, a_row, a_swz, wm * (TM / 2) + i * 16);
@@ -627,6 +668,14 @@ __global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_f16_kern
     conv_wgrad_dma_body<f16_t, TM, TN, false>(p, chunk_pixels);
 }
 template <int TM, int TN>
+__global__ void __launch_bounds__(256, 3) conv_wgrad_dma_f32_kernel(const MpnWgradParams p, long chunk_pixels) {
+    conv_wgrad_dma_body<float, TM, TN, false>(p, chunk_pixels);
+}
+template <int TM, int TN>
+__global__ void __launch_bounds__(256, 3) conv_wgrad_dma_lin_f32_kernel(const MpnWgradParams p, long chunk_pixels) {
+    conv_wgrad_dma_body<float, TM, TN, false, false, true>(p, chunk_pixels);
+}
+template <int TM, int TN>
 __global__ void __launch_bounds__(256, TM > 128 ? 2 : 3) conv_wgrad_dma_seg_kernel(const MpnWgradParams p, long chunk_pixels) {
     conv_wgrad_dma_body<bf16_t, TM, TN, true, false, true>(p, chunk_pixels);     // pyramid levels are dense stride-1 "same" convolutions (mpn_conv_wgrad checks)
 }
@@ -714,7 +763,10 @@ inline bool wgrad_uses_dma(const MpnWgradParams& p) {
             if (pl * p.x_sW > xb) xb = pl * p.x_sW;
         }
     }
-    const bool small = xb * 2 < 0x7fffffffL && P * p.dy_sP * 2 < 0x7fffffffL;
+    const long es = p.dtype == MPN_F32 ? 4 : 2;
+    const bool small = xb * es < 0x7fffffffL && P * p.dy_sP * es < 0x7fffffffL;
+    // f32 (round 5): the same LDS-DMA ring feeding the exact-fp32 MFMA; single dense tensors only (no pyramid / virtual concatenation)
+    if (p.dtype == MPN_F32) return use_dma && mpn_tune("MPN_WGRAD_F32_DMA", 1) != 0 && small && p.nseg == 0 && p.kseg_n == 0 && p.Cin % 4 == 0;
     return (p.dtype == MPN_BF16 || p.dtype == MPN_F16) && use_dma && small && p.Cin % 8 == 0;
 }
 
@@ -725,7 +777,8 @@ inline bool wgrad_lin_ok(const MpnWgradParams& p) {
     // the tap offset moves into the x descriptor (base + tap, num_records = bytes - tap): a NEGATIVE tap lengthens the range by up to
     // (pad W + pad) pixels, and the descriptor holds 2^31 - 1 bytes at most — beyond that the launch takes the gather kernel instead of
     // a clamped descriptor that would zero-fill valid rows at the tail
-    const int64_t reach = (int64_t)p.B * p.x_sB * 2 + ((int64_t)p.pad * p.W + p.pad) * p.x_sW * 2;
+    const int64_t es = p.dtype == MPN_F32 ? 4 : 2;
+    const int64_t reach = (int64_t)p.B * p.x_sB * es + ((int64_t)p.pad * p.W + p.pad) * p.x_sW * es;
     if (reach >= 0x7fffffffLL) return false;
     return on && p.kseg_n == 0 && p.stride == 1 && p.Ho == p.H && p.Wo == p.W && p.x_sH == (int64_t)p.W * p.x_sW && p.x_sB == (int64_t)p.H * p.x_sH;
 }
@@ -768,7 +821,17 @@ int launch_wgrad(const MpnWgradParams& p, hipStream_t st, bool reduce = true) {
     if ((ablate & 1) && p.chunks > 1) reduce = false;
     int rc;
     const dim3 g((unsigned)grid), blk(256);
-    if (sizeof(T) == 2 && wgrad_uses_dma(p)) {
+    if (sizeof(T) == 4 && wgrad_uses_dma(p)) {
+#define MPN_WGRAD_DMA_LAUNCH_F32(KERNEL)                                                                                 \
+        if (tm == 128 && tn == 128) hipLaunchKernelGGL((KERNEL<128, 128>), g, blk, 0, st, p, chunk_pixels);              \
+        else if (tm == 128) hipLaunchKernelGGL((KERNEL<128, 64>), g, blk, 0, st, p, chunk_pixels);                       \
+        else if (tn == 128) hipLaunchKernelGGL((KERNEL<64, 128>), g, blk, 0, st, p, chunk_pixels);                       \
+        else hipLaunchKernelGGL((KERNEL<64, 64>), g, blk, 0, st, p, chunk_pixels)
+        if (wgrad_lin_ok(p)) { MPN_WGRAD_DMA_LAUNCH_F32(conv_wgrad_dma_lin_f32_kernel); }
+        else { MPN_WGRAD_DMA_LAUNCH_F32(conv_wgrad_dma_f32_kernel); }
+#undef MPN_WGRAD_DMA_LAUNCH_F32
+        rc = mpn_launch_status();
+    } else if (sizeof(T) == 2 && wgrad_uses_dma(p)) {
 #define MPN_WGRAD_DMA_LAUNCH(KERNEL)                                                                                     \
         if (tm == 256) hipLaunchKernelGGL((KERNEL<256, 128>), g, blk, 0, st, p, chunk_pixels);                           \
         else if (tm == 128 && tn == 128) hipLaunchKernelGGL((KERNEL<128, 128>), g, blk, 0, st, p, chunk_pixels);         \
@@ -846,8 +909,9 @@ extern "C" int mpn_conv_wgrad_chunks(const MpnWgradParams* p) {
     const long tiles = (long)((p->Cin + tm - 1) / tm) * ((p->Cout + tn - 1) / tn) * p->R * p->S;
     const long P = wgrad_total_pixels(*p);
     static const long target16 = mpn_tune("MPN_WGRAD_TARGET", kWgradTarget);
-    // f32 (register-staged parity kernel, matrix-pipe bound): three workgroups per CU's worth of slices (cfg2 55.7 -> 55.1 ms; 256: 62.3)
-    const long target = (p->dtype == MPN_F32 && target16 == kWgradTarget) ? 768 : target16;
+    // f32 launches that fall back to the register-staged generic kernel (matrix-pipe bound, no DMA ring): three workgroups per CU's worth
+    // of slices (cfg2 55.7 -> 55.1 ms; 256: 62.3); on the ring 512 and 768 measure the same (52.06 / 52.08 ms), 1024 worse
+    const long target = (p->dtype == MPN_F32 && !wgrad_uses_dma(*p) && target16 == kWgradTarget) ? 768 : target16;
     static const long minpix = mpn_tune("MPN_WGRAD_MINPIX", 512);
     // ~2 workgroups per CU (long slices run near peak, partial-sum traffic dominates beyond) and NEVER one more than that: rounding the
     // slice count up put 540 workgroups on the 512 slots of the 3x3 256-channel layers — the 28 that share a CU three ways finish last,

@@ -624,7 +624,7 @@ def conv_wgrad(x, dy, dw, Cout, R, S, stride, pad, cin=None, x_geom=None, db=Non
         e0 = KERNEL_EVENTS.begin()
         call("mpn_conv_wgrad_partials" if chunks > 1 else "mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
         dts = dtype_name(dt)
-        name = ("conv_wgrad_dma%s%s_kernel<%d, %d>" % ("_lin" if (kid & 2) else "", "_f16" if dt == torch.float16 else "", kid >> 16, (kid >> 4) & 0xfff) if (kid & 1)
+        name = ("conv_wgrad_dma%s%s_kernel<%d, %d>" % ("_lin" if (kid & 2) else "", {torch.float16: "_f16", torch.float32: "_f32"}.get(dt, ""), kid >> 16, (kid >> 4) & 0xfff) if (kid & 1)
                 else "conv_wgrad_kernel<%s, %d, %d>" % (dts, kid >> 16, (kid >> 4) & 0xfff))
         if KERNEL_EVENTS.detail:
             es = 2 if is16(dt) else 4

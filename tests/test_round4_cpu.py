@@ -124,7 +124,7 @@ def _hot_kernels():
         hot.append((mangled("conv_igemm_kernel", dt, 128, 128, True, True, False, False), 3, 49152))
         hot.append((mangled("conv_igemm_s3_kernel", dt, 128, 128, True, True, False, False), 3, 49152))
     for tm, tn, lds in ((128, 128, 49152), (128, 64, 36864), (64, 128, 36864), (64, 64, 24576)):
-        for suffix in ("", "_f16"):
+        for suffix in ("", "_f16") + (("_f32",) if tm <= 128 else ()):      # round 5: the f32 twins (exact-fp32 MFMA on the same ring)
             hot.append((mangled("conv_wgrad_dma%s_kernel" % suffix, tm, tn), 3, lds))
             hot.append((mangled("conv_wgrad_dma_lin%s_kernel" % suffix, tm, tn), 3, lds))      # the instantiation nearly every launch of the step takes
     hot.append((mangled("conv_wgrad_dma_seg_kernel", 128, 128), 3, 49152))

@@ -368,15 +368,17 @@ def test_bf16_pyramids_heads_and_stem_against_the_rounding_oracle():
     ((2, 16, 16, 64, 64, 3, 1, 2), "dma"),     # strided: the general gather
     ((2, 12, 12, 64, 64, 3, 0, 1), "dma"),     # "valid" convolution (output smaller than input): the general gather
 ])
-def test_wgrad_instantiations_match_torch(case):
-    """layers.py / fpn.py convolutions, weight gradient (torch autograd is the reference).  Round 4 added the LIN instantiation of the LDS-DMA
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_wgrad_instantiations_match_torch(case, dtype):
+    """layers.py / fpn.py convolutions, weight gradient (torch autograd is the reference).  float32 (round 5): the same LDS-DMA ring feeding the
+    exact-fp32 MFMA — 16-pixel k-steps, [k][channel] tiles read with ds_read_b32 through their own bank swizzle — in the general-gather and
+    linear-addressing forms; every shape below runs through it as well (tolerance: the f32 kernel tolerance, 2e-4 of the reference's max).  Round 4 added the LIN instantiation of the LDS-DMA
     kernel (stride-1 same-extent convolutions over a dense x: tap offset in the buffer descriptor, k-step advance in the scalar offset,
     only the halo predicate per lane).  Shapes chosen for what that changes: borders in every k-step, k-steps spanning images, rows before
     and past the tensor, slices cut inside images, ragged tiles; and the shapes that must NOT take it.  (The same cases also passed on the
     shared-tap 3x3 kernel of tools/experiments_r4/wgrad_shared_tap_s3.patch, which was measured and not kept.)"""
     from multiposenet.pytorch_amd import ops
     (B, H, W, Cin, Cout, k, pad, stride), kind = case
-    dtype = torch.bfloat16
     x = rnd(dtype, rng_normal(51, B, Cin, H, W))
     w = rnd(dtype, rng_normal(52, Cout, Cin, k, k) / float(np.sqrt(Cin * k * k))).requires_grad_(True)
     y = F.conv2d(x, w, None, stride=stride, padding=pad)
@@ -390,7 +392,8 @@ def test_wgrad_instantiations_match_torch(case):
         names = [r[0] for r in ops.KERNEL_EVENTS.rec]
     finally:
         ops.KERNEL_EVENTS.disable()
-    prefix = {"lin": "conv_wgrad_dma_lin_kernel<", "dma": "conv_wgrad_dma_kernel<"}[kind]
+    sfx = "_f32" if dtype == torch.float32 else ""
+    prefix = {"lin": "conv_wgrad_dma_lin%s_kernel<" % sfx, "dma": "conv_wgrad_dma%s_kernel<" % sfx}[kind]
     assert names and names[0].startswith(prefix), names
     check_close("wgrad %s %s" % (kind, case[0]), dw.cpu().permute(0, 3, 1, 2), w.grad, dtype)
     if fused:
