@@ -147,22 +147,6 @@ __device__ __forceinline__ void store_partial(float* dst, float a, float b, bool
 // were built in round 3, measured 0.2 - 0.3 ms/step SLOWER than the separate finalize launch for the larger layers, and removed in
 // round 4: DESIGN.md section 5.)
 
-template <typename E2, int SL>
-__device__ __forceinline__ void fin_sum_rows(const E2* __restrict__ col, long stride, int r0, int r1, int sl, double& s1, double& s2) {
-    int r = r0 + sl;
-    for (; r + 7 * SL < r1; r += 8 * SL) {                     // eight loads in flight per thread
-        E2 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = col[(long)(r + u * SL) * stride];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
-    }
-    for (; r < r1; r += SL) {
-        const E2 v = col[(long)r * stride];
-        s1 += (double)v.x; s2 += (double)v.y;
-    }
-}
-
 // true for the workgroup that drew ticket `last` of `counter` (which it leaves at zero again)
 __device__ __forceinline__ bool fin_ticket(unsigned* counter, unsigned last, volatile int* flag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its write-through stores
@@ -181,26 +165,46 @@ __device__ __forceinline__ bool fin_ticket(unsigned* counter, unsigned last, vol
 
 template <int TC>
 __device__ __forceinline__ void fin_last_arriver(const MpnConvParams& p, int c0, int tc, int tp, int ntiles, unsigned char* lds) {
-    constexpr int SL = 256 / TC;                               // slices per channel (256 threads)
+    // Round 5: the column block [ntiles][TC] is read as 16-byte pieces (two channels' (sum, sum^2)) by 256 / (TC / 2) row slices, eight
+    // loads in flight per thread — half the dependent round trips of the 8-byte / (256 / TC)-slice form it replaces (225 tiles at
+    // TC = 128: 8 instead of 15), which is the whole cost of this tail.  Fixed order (slice-sequential rows, slices combined in order):
+    // the same numbers whichever workgroup arrives last.
+    constexpr int QL = TC / 2, SL = 256 / QL;
     volatile int* flag = reinterpret_cast<volatile int*>(lds + 12288);
-    double* lds_d = reinterpret_cast<double*>(lds);            // [SL][TC][2]
+    double* lds_d = reinterpret_cast<double*>(lds);            // [SL][TC][2] = 8 KB
     const int t = threadIdx.x;
     const float* __restrict__ part = p.stats ? p.stats : p.bnb_partial;
-    const int cl = t % TC, sl = t / TC;
+    const int cl = t % TC, sl0 = t / TC;                       // finishing role: one thread per channel (sl0 == 0)
     const int c = c0 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (!fin_ticket(p.fin_counters + tc, (unsigned)(ntiles - 1), flag)) return;
-    if (c < p.Cout) fin_sum_rows<float2, SL>(reinterpret_cast<const float2*>(part) + c, (long)p.Cout, 0, ntiles, sl, s1, s2);
-    if (SL > 1) {
-        lds_d[(sl * TC + cl) * 2 + 0] = s1;
-        lds_d[(sl * TC + cl) * 2 + 1] = s2;
+    {
+        const int q = t % QL, sl = t / QL;
+        const bool on = c0 + 2 * q + 1 < p.Cout;                // Cout is even (launcher): the pair exists or does not
+        const float4* __restrict__ col = reinterpret_cast<const float4*>(part + (long)c0 * 2) + q;
+        const long rs = (long)p.Cout / 2;                       // float4 per table row (launcher: in-launch finalize needs an even Cout)
+        double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
+        if (on) {
+            for (int r0 = sl; r0 < ntiles; r0 += 8 * SL) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = r0 + u * SL;
+                    v[u] = r < ntiles ? col[(long)r * rs] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { a1 += (double)v[u].x; a2 += (double)v[u].y; b1 += (double)v[u].z; b2 += (double)v[u].w; }
+            }
+        }
+        lds_d[(sl * TC + 2 * q) * 2 + 0] = a1; lds_d[(sl * TC + 2 * q) * 2 + 1] = a2;
+        lds_d[(sl * TC + 2 * q + 1) * 2 + 0] = b1; lds_d[(sl * TC + 2 * q + 1) * 2 + 1] = b2;
         __syncthreads();
-        if (sl == 0) {
-            s1 = 0.0; s2 = 0.0;
+        if (t < TC) {
 #pragma unroll
             for (int k = 0; k < SL; ++k) { s1 += lds_d[(k * TC + cl) * 2 + 0]; s2 += lds_d[(k * TC + cl) * 2 + 1]; }
         }
     }
+    const int sl = sl0;
     if (sl == 0 && c < p.Cout) {
         const int C = p.Cout;
         const float gm = p.fin_gamma ? p.fin_gamma[c] : 1.f;
@@ -1129,6 +1133,7 @@ extern "C" int mpn_conv_forward(const MpnConvParams* pp, void* stream) {
     MPN_CHECK_ARG(!p.res_mask || (p.res_mode == 1 && !p.nseg && p.y_sB == (int64_t)p.Ho * p.Wo * p.y_sP && p.y_sP == p.Cout_store));
     MPN_CHECK_ARG(!(p.stats && (p.bias || p.scale || p.res_mode || p.accumulate || p.act)));
     MPN_CHECK_ARG(!((p.res_mode || p.accumulate) && p.act && p.act != 3));
+    MPN_CHECK_ARG(!p.fin_counters || (p.Cout % 2) == 0);       // the last arriver reads the partial table in 16-byte pieces
     MPN_CHECK_ARG(!p.fin_counters || (((p.stats != nullptr) != (p.bnb_partial != nullptr)) && p.fin_count > 0 && !p.nseg &&
                                       (p.stats ? p.fin_out != nullptr : true)));
     MPN_CHECK_ARG(!p.bnb_partial || (p.bnb_y && p.bnb_mean && p.bnb_invstd && !p.out_f32 && !p.nseg && !p.stats && !p.act &&
