@@ -14,7 +14,7 @@ cd $R
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-events $FLAGS 2>/dev/null | tail -1 > $O/bench.json
 DB=$(find $O/serial -name "*_results.db" | head -1)
 # bench: 2 set-up (1 eager + 1 recording) + 2 warm-up + 6 timed + 5 empty-queue host measurements = 15 steps
-python tools/rocprof_summary.py "$DB" 15 "round 4, serial schedule (MPN_SIDE_STREAM=0), python bench.py --steps 6 --warmup 2 $FLAGS (15 steps incl. set-up and the host measurements), rocprofv3 --kernel-trace --stats" > $O/kernel_trace_serial.txt 2>&1
+python tools/rocprof_summary.py "$DB" 15 "round 5, serial schedule (MPN_SIDE_STREAM=0), python bench.py --steps 6 --warmup 2 $FLAGS (15 steps incl. set-up and the host measurements), rocprofv3 --kernel-trace --stats" > $O/kernel_trace_serial.txt 2>&1
 F=$(find $O/FETCH_SIZE -name "*_results.db" | head -1); W=$(find $O/WRITE_SIZE -name "*_results.db" | head -1)
 python tools/pmc_summary.py "$F" "$W" 11 $O/pmc_hbm_traffic.json > $O/pmc_hbm_traffic.txt 2>&1
 python - <<PY
