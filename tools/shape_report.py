@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-shape table of the conv launches of one R101 480x480 B=32 bf16 train step (HIP events around every launch):
-calls, time, TFLOP/s and algorithmic GB/s per distinct (kind, geometry).  Run on the GPU box."""
+"""Per-shape table of the conv launches of one train step (HIP events around every launch): calls, time, TFLOP/s and algorithmic GB/s per
+distinct (kind, geometry).  Default: R101 train_both 480x480 B=32 bf16; SR_LAYERS / SR_SIZE / SR_BATCH / SR_DTYPE / SR_SUBNET select another
+configuration (cfg2: SR_LAYERS=50 SR_BATCH=16 SR_DTYPE=f32 SR_SUBNET=keypoint_subnet).  Run on the GPU box."""
 import os
 import sys
 
@@ -15,17 +16,21 @@ from multiposenet.pytorch_amd.optim import FusedAdam
 
 def main():
     dev = torch.device("cuda:0")
-    model = poseNet(101, compute_dtype=torch.bfloat16).to(dev)
+    layers, size, batch = int(os.environ.get("SR_LAYERS", "101")), int(os.environ.get("SR_SIZE", "480")), int(os.environ.get("SR_BATCH", "32"))
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[os.environ.get("SR_DTYPE", "bf16")]
+    subnet = os.environ.get("SR_SUBNET", "train_both")
+    model = poseNet(layers, compute_dtype=dtype).to(dev)
     bench.he_weights(model)
     for p in model.prn.parameters():
         p.requires_grad = False
     model.train()
     opt = FusedAdam(model, lr=1e-4, weight_decay=0.0)
-    img, heat, wgt, anno = bench.synth(32, 480, dev, seed=100)
+    img, heat, wgt, anno = bench.synth(batch, size, dev, seed=100)
+    gts = {"train_both": ["train_both", heat, wgt, anno], "keypoint_subnet": ["keypoint_subnet", heat, wgt], "detection_subnet": ["detection_subnet", anno]}[subnet]
 
     def step():
-        pred, (ks, ds) = model([img, "train_both"])
-        loss, log = poseNet.build_loss((ks, ds), "train_both", heat, wgt, anno)
+        pred, saved = model([img, subnet])
+        loss, log = poseNet.build_loss(saved, *gts)
         opt.zero_grad()
         loss.backward()
         opt.step()
@@ -48,7 +53,7 @@ def main():
         rows.append((ms, key, calls, us, d["flops"] / d["n"] / us / 1e6, float(byts) / us / 1e3))
     rows.sort(reverse=True)
     tot = sum(r[0] for r in rows)
-    print("# conv launches by shape, R101 train_both 480x480 B=32 bf16; total %.2f ms/step (event-bracketed)" % tot)
+    print("# conv launches by shape, R%d %s %dx%d B=%d %s; total %.2f ms/step (event-bracketed)" % (layers, subnet, size, size, batch, os.environ.get("SR_DTYPE", "bf16"), tot))
     print("%-58s %6s %9s %9s %8s %9s" % ("shape", "calls", "ms/step", "avg_us", "TF/s", "GB/s(alg)"))
     for ms, key, calls, us, tf, gb in rows:
         print("%-58s %6.1f %9.3f %9.1f %8.1f %9.1f" % (key, calls, ms, us, tf, gb))
