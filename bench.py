@@ -40,7 +40,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # one hardware queue per str
 import numpy as np
 import torch
 
-GFLOP_PER_IMG_TRAIN = {("r101", 480): 608.6, ("r50", 480): 343.7}    # BASELINE.md section 3 (algorithmic, 3 x fwd)
+# BASELINE.md section 3 (algorithmic, 3 x fwd): (layers, size, subnet) -> GFLOP per image of one training step
+GFLOP_PER_IMG_TRAIN = {(101, 480, "train_both"): 608.6, (50, 480, "keypoint_subnet"): 343.7, (101, 800, "train_both"): 1690.2,
+                       (50, 256, "keypoint_subnet"): 97.8}
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 
@@ -65,6 +67,10 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and the gradient reducer even with one rank")
+    ap.add_argument("--rccl-channels", type=int, default=0,
+                    help="N > 0: NCCL_MIN_NCHANNELS = NCCL_MAX_NCHANNELS = N before the process group comes up (each channel is a "
+                         "workgroup taken from the compute kernels); 0 = the library's choice.  Echoed in the line's dist block")
+    ap.add_argument("--init-timeout", type=int, default=120, help="seconds a rank waits for rendezvous / the first collective")
     ap.add_argument("--shared-device-test", action="store_true",
                     help="TEST SWITCH, NOT A MEASUREMENT: run the N ranks of --gpus N on ONE device over gloo (RCCL refuses two ranks on one "
                          "GPU), so that the spawn -> rendezvous -> data-parallel step -> one-JSON-line path executes on a 1-GPU box; the line "
@@ -123,12 +129,12 @@ def cpu_baseline_worker(args):
             leaves.append(v)
     opt = torch.optim.Adam(leaves, lr=1e-4)
 
-    def run(B, S, nsteps):
+    def run(B, S, warm, nsteps):
         img = torch.from_numpy(weightgen.gen_images(1, B, S, S))
         heat, wgt = weightgen.gen_keypoint_gt(1, B, S // 4, S // 4)
         anno = torch.from_numpy(weightgen.gen_boxes_gt(1, B, S, max_n=8))
         ts = []
-        for i in range(nsteps + 1):
+        for i in range(warm + nsteps):
             t0 = time.time()
             pred, (ks, ds) = po.posenet_forward(params, img, "train_both", args.layers, True)
             l1, _ = po.keypoint_loss(ks, torch.from_numpy(heat), torch.from_numpy(wgt))
@@ -137,18 +143,27 @@ def cpu_baseline_worker(args):
             (l1 + l2).backward()
             opt.step()
             ts.append(time.time() - t0)
-        return min(ts[1:])          # first step pays oneDNN primitive creation
+        ts = sorted(ts[warm:])          # the first steps pay oneDNN primitive creation
+        return ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
 
+    # 2 warm-up + 5 timed steps, median.  A 160x160 calibration step decides whether that protocol at the
+    # full size fits the time box (7 steps + slack <= 150 s); otherwise fewer timed steps, never fewer than one, and said so.
     B = args.cpu_batch
-    t_small = run(B, 160, 1)
+    t_small = run(B, 160, 1, 1)
     est_full = t_small * (args.size / 160.0) ** 2
-    if est_full * 2.2 <= 60.0:
-        t_full = run(B, args.size, 1)
-        out = {"value": round(B / t_full, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-               "sample": "oracle torch-CPU restatement, R%d train_both %dx%d, batch %d, 1 timed step (fwd+losses+bwd+Adam), fp32, %d threads"
-                         % (args.layers, args.size, args.size, B, cores)}
+    if est_full * 7.5 <= 150.0:
+        warm, nsteps = 2, 5
+    elif est_full * 3.3 <= 150.0:
+        warm, nsteps = 1, 2
     else:
-        out = {"value": round(B / est_full, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+        warm, nsteps = 0, 0
+    if nsteps:
+        t_full = run(B, args.size, warm, nsteps)
+        out = {"value": round(B / t_full, 4), "unit": "images/sec", "cores": cores, "kind": "port", "steps": nsteps, "warmup": warm,
+               "sample": "oracle torch-CPU restatement, R%d train_both %dx%d, batch %d, %d warm-up + %d timed steps (fwd+losses+bwd+Adam), "
+                         "median %.3f s/step, fp32, %d threads" % (args.layers, args.size, args.size, B, warm, nsteps, t_full, cores)}
+    else:
+        out = {"value": round(B / est_full, 4), "unit": "images/sec", "cores": cores, "kind": "port", "steps": 1, "warmup": 1,
                "sample": "oracle torch-CPU restatement, R%d train_both at 160x160 batch %d (%.1f s/step), scaled by pixel count to %dx%d; "
                          "the full-size step would exceed the time box; fp32, %d threads" % (args.layers, B, t_small, args.size, args.size, cores)}
     print("CPU_BASELINE " + json.dumps(out), flush=True)
@@ -168,13 +183,23 @@ def cpu_baseline(args):
         return {"value": None, "unit": "images/sec", "cores": host_cores(), "kind": "port", "sample": "timed out after 240 s"}
 
 
-def pmc_traffic(kernel_class):
+def config_tag(args):
+    """'' for the headline configuration (BASELINE config 3), 'cfg2' / 'cfg4' for the flags that name those configurations, else None."""
+    key = (args.layers, args.size, args.batch, args.dtype, args.subnet)
+    return {(101, 480, 32, "bf16", "train_both"): "", (50, 480, 16, "f32", "keypoint_subnet"): "cfg2",
+            (101, 800, 8, "bf16", "train_both"): "cfg4"}.get(key)
+
+
+def pmc_traffic(kernel_class, tag=""):
     """HBM bytes per launch of the dominant kernel from the last committed rocprofv3 --pmc passes
-    (profiles/r*_pmc_hbm_traffic.json, made by tools/pmc_summary.py: FETCH_SIZE and WRITE_SIZE in separate runs,
-    reads doubled per MI355X_MICROARCH.md).  PMC collection serialises kernels, so it cannot run inside the timed
-    bench; None when no profile is present."""
+    (profiles/r*_pmc_hbm_traffic.json, r*_cfg2_… / r*_cfg4_… for those configurations; made by tools/pmc_summary.py: FETCH_SIZE and
+    WRITE_SIZE in separate runs, reads doubled per MI355X_MICROARCH.md).  PMC collection serialises kernels, so it cannot run
+    inside the timed bench; None when no profile of THIS configuration is present."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_hbm_traffic.json")))      # the headline configuration's (others carry a config tag)
+    if tag is None:
+        return None, None
+    pat = "r[0-9][0-9]_%spmc_hbm_traffic.json" % (tag + "_" if tag else "")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
     if not files:
         return None, None
     try:
@@ -243,10 +268,30 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
-        if args.shared_device_test:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.rccl_channels > 0:
+            os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_channels)
+        import datetime
+        tmo = datetime.timedelta(seconds=max(10, args.init_timeout))
+        try:
+            if args.shared_device_test:
+                dist.init_process_group("gloo", timeout=tmo)
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=tmo)
+            probe = torch.ones(1, device="cpu" if args.shared_device_test else torch.device("cuda", local))
+            dist.all_reduce(probe)                    # the first collective builds the communicator: fail HERE, with a diagnosis
+            if not args.shared_device_test:
+                torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError("first all-reduce summed to %d over %d ranks" % (int(probe.item()), world))
+        except Exception as e:      # noqa: BLE001 — any rendezvous / communicator failure: one line, exit status 3, no JSON
+            sys.stderr.write("bench.py: rank %d/%d could not join the process group within %d s (MASTER_ADDR=%s MASTER_PORT=%s, backend %s, "
+                             "HSA_ENABLE_IPC_MODE_LEGACY=%s, NCCL_DEBUG=%s): %s: %s\n"
+                             % (rank, world, max(10, args.init_timeout), os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"),
+                                "gloo" if args.shared_device_test else "nccl", os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                                os.environ.get("NCCL_DEBUG", "unset"), type(e).__name__, str(e).splitlines()[0][:300] if str(e) else ""))
+            sys.stderr.flush()
+            os._exit(3)
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -317,12 +362,19 @@ def main():
         except Exception:           # noqa: BLE001 — a build without the binding: say so instead of failing the bench
             rccl = "unavailable"
         dist_info = {"backend": backend, "world_size": dist.get_world_size(), "rccl_version": rccl,
+                     "rccl_channels": args.rccl_channels if args.rccl_channels > 0 else "library default",
+                     "env": {k: os.environ.get(k, "unset") for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_DEBUG", "NCCL_ALGO",
+                                                                      "NCCL_PROTO", "HSA_ENABLE_IPC_MODE_LEGACY", "GPU_MAX_HW_QUEUES", "MPN_BUCKET_MB",
+                                                                      "MPN_BUCKET_ADAM")},
                      "buckets": len(reducer.buckets), "bucket_mb": reducer.bucket_mb, "collectives_per_step": reducer.launched,
+                     "optimizer_updates_behind_buckets": reducer.updated,
                      "gradient_bytes_per_step": int(sum(b["end"] - b["start"] for b in reducer.buckets) * 4),
                      "per_rank_ms": [r["ms_per_step"] for r in sorted(per_rank, key=lambda r: r["rank"])],
                      "allreduce_ms_exposed": [r["allreduce_ms_exposed"] for r in sorted(per_rank, key=lambda r: r["rank"])],
                      "allreduce_ms_exposed_how": "HIP events on the launch stream around the waits of GradReducer.finish() in the last timed "
-                                                 "step: GPU time between the end of backward and the last collective's completion"}
+                                                 "step: GPU time between the end of backward and the completion of the last collective AND "
+                                                 "of the last bucket's Adam update (per-bucket updates run behind each all-reduce on the "
+                                                 "finishing stream)"}
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.shared_device_test else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -400,14 +452,14 @@ def main():
                                 if k in ("heatmap_loss", "total_loss", "classification_loss", "regression_loss")}   # not waited for
         out["host_enqueue_ms_per_step"] = round(host_free[len(host_free) // 2] * 1000.0, 3)      # empty queue, median of 5
         out["host_enqueue_ms_per_step_in_region"] = round(t_enq / args.steps * 1000.0, 3)       # queue full: follows the GPU
-        gf = GFLOP_PER_IMG_TRAIN.get(("r%d" % args.layers, args.size)) if args.subnet == ("keypoint_subnet" if args.layers == 50 else "train_both") else None
+        gf = GFLOP_PER_IMG_TRAIN.get((args.layers, args.size, args.subnet))
         if gf is not None:
             out["model_tflops_per_gpu"] = round(ips / world * gf / 1000.0, 2)
         if ke_serial:
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
             name, d = max(ke_serial.items(), key=lambda kv: kv[1]["ms"])
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-            traffic, traffic_src = pmc_traffic(name)
+            traffic, traffic_src = pmc_traffic(name, config_tag(args))
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                                "launches": d["n"], "avg_launch_us": round(d["ms"] * 1000.0 / max(d["n"], 1), 2),

@@ -225,7 +225,21 @@ def call(name, *args):
 def gpu_op(fn, *args):
     """A device-side operation that is not a C-ABI launch (event record / stream wait, a collective, a tiny torch op on
     static tensors): run it and, while a step is being recorded, remember it for replay."""
-    out = fn(*args)
-    if TAPE is not None:
-        TAPE.append((fn, args, False))
+    global TAPE
+    tape, TAPE = TAPE, None          # launches made INSIDE fn belong to fn: replaying fn re-issues them, so they are not recorded twice
+    try:
+        out = fn(*args)
+    finally:
+        TAPE = tape
+    if tape is not None:
+        tape.append((fn, args, False))
     return out
+
+
+def call_raw(name, *args):
+    """A C-ABI launch issued from inside a gpu_op closure (e.g. the per-bucket Adam update behind a collective): never recorded
+    on its own — the enclosing closure is what the launch list holds."""
+    st = getattr(lib(), name)(*args)
+    if st != 0:
+        raise MpnError("%s failed with status %d" % (name, st))
+    return 0

@@ -17,7 +17,14 @@ DataParallel), computes its local-mean loss, and only gradients cross xGMI:
     stream after it has been made to wait for the main one) and overlaps the remaining dgrad/wgrad work.
     Buckets complete in reverse-forward order (heads -> FPN -> layer4 ... conv1);
   * ``finish()`` waits for the outstanding handles and averages (``ReduceOp.AVG`` on RCCL; SUM then
-    an in-place scale on backends without AVG, e.g. gloo in the CPU tests).
+    an in-place scale on backends without AVG, e.g. gloo in the CPU tests);
+  * **per-bucket optimizer update** (round 6): when the step owns its optimizer (the recorded step, replay.py) the reducer is
+    given ``on_bucket`` — FusedAdam's slice update.  Each bucket then goes through a third HIP stream, the *finishing stream*:
+    it waits for the two producing streams (events, no stall on either), carries the collective, waits for it, and runs
+    ``mpn_adam_step_dev`` over exactly that arena slice.  Backward never waits for a collective, the weight-gradient stream
+    never waits for one either, and ``finish()`` only joins the finishing stream: what is exposed at N > 1 is the LAST
+    bucket's all-reduce + its update, not the last all-reduce + a whole-arena Adam.  ``GradReducer(arena, local=True)`` is
+    the same schedule without a process group (one GPU): the Adam update of a bucket runs under the rest of backward.
 
 Equal shard sizes => the average of local-mean gradients equals the gradient of the global mean
 (SURVEY.md 8e).  Parameters and BN buffers are broadcast from rank 0 once at attach time.
@@ -31,26 +38,38 @@ from ._lib import gpu_op
 
 
 class GradReducer(object):
-    def __init__(self, arena, process_group=None, bucket_mb=32.0, param_filter=None):
+    def __init__(self, arena, process_group=None, bucket_mb=32.0, param_filter=None, local=False):
         self.arena = arena
         self.pg = process_group
-        self.world = dist.get_world_size(process_group)
+        self.local = bool(local)       # no process group: only the readiness schedule (per-bucket optimizer updates on one GPU)
+        self.world = 1 if self.local else dist.get_world_size(process_group)
         self.bucket_elems = max(1, int(bucket_mb * 1024 * 1024 / 4))
         self.buckets = []          # dict(start, end, params:set(idx), pending:int, handle)
         self.param_bucket = {}
         self._build()
         self.handles = []
         self.launched = 0
-        backend = dist.get_backend(process_group)
+        backend = "local" if self.local else dist.get_backend(process_group)
+        self.backend = backend
         self.use_avg = backend == "nccl"
         # gloo (debug / single-GPU tests) reduces host memory: device buckets are staged through pinned buffers
-        self.stage_host = backend != "nccl" and arena.device.type == "cuda"
+        self.stage_host = backend == "gloo" and arena.device.type == "cuda"
         self.launch_stream = None      # set by the engine when weight gradients are produced on a side stream
         self.pre_launch = None         # engine hook: hand over side-stream work still waiting for a fork point
         self._trainable_sig = tuple(p.requires_grad for p in arena.params)
         self.bucket_mb = float(bucket_mb)
         self.measure = False           # bench.py: bracket finish()'s waits with a pair of timing events (exposed_ms)
         self._ev = None
+        # per-bucket optimizer update: callable(start, end, raw stream handle) set for the duration of one backward pass by the
+        # step that owns the optimizer (replay.py); None = gradients only (the caller steps the optimizer after backward)
+        self.on_bucket = None
+        self._finish_stream = None     # third stream: wait for both producers -> collective -> wait -> update, per bucket
+        self.updated = 0               # buckets updated through on_bucket in the current / last step
+
+    def finishing_stream(self):
+        if self._finish_stream is None:
+            self._finish_stream = torch.cuda.Stream(device=self.arena.device)
+        return self._finish_stream
 
     def _build(self):
         ar = self.arena
@@ -81,7 +100,11 @@ class GradReducer(object):
         return tuple((b["start"], b["end"]) for b in self.buckets)
 
     # ---- called by the engine -------------------------------------------------------------------
-    def begin(self):
+    def begin(self, on_bucket=None):
+        """Start of a backward pass.  ``on_bucket`` (callable(start, end, raw stream handle) or None) is the optimizer's slice update
+        when the step owns its optimizer; it is an ARGUMENT so that a recorded step re-installs it on every replay and an eager
+        ``loss.backward()`` in between (which steps its optimizer afterwards) clears it."""
+        self.on_bucket = on_bucket
         if tuple(p.requires_grad for p in self.arena.params) != self._trainable_sig:
             # parameters were (un)frozen after attach(): buckets cover trainable parameters only, so rebuild them — the
             # same change must be made on every rank (the bucket list is the collective schedule)
@@ -92,6 +115,7 @@ class GradReducer(object):
             bk["pending"] = len(bk["params"])
         self.handles = []
         self.launched = 0
+        self.updated = 0
 
     def param_ready(self, p):
         i = self.arena.index.get(id(p))
@@ -101,21 +125,34 @@ class GradReducer(object):
         bk = self.buckets[b]
         bk["pending"] -= 1
         if bk["pending"] == 0:
+            if self.pre_launch is not None:
+                self.pre_launch()              # side-stream work still waiting for a fork point (recorded on its own)
             gpu_op(self._launch, bk)           # (recordable: replay.py re-issues the collective at this point of the step)
 
     def _launch(self, bk):
-        if self.pre_launch is not None:
-            self.pre_launch()
         view = self.arena.grad_flat[bk["start"]: bk["end"]]
         op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
+        self.launched += 1
+        bk["pending"] = -1
+        if self.on_bucket is not None:
+            if view.is_cuda:
+                self._launch_and_update(bk, view, op)
+            else:                                   # host arena (the gloo CPU tests): same schedule, nothing to overlap
+                if not self.local:
+                    dist.all_reduce(view, op=op, group=self.pg)
+                    if not self.use_avg:
+                        view.mul_(1.0 / self.world)
+                self.on_bucket(bk["start"], bk["end"], 0)
+                self.updated += 1
+            return
+        if self.local:
+            return
         if self.stage_host:
             if self.launch_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.launch_stream)
             host = view.cpu()                       # synchronises with the producing kernels
             h = dist.all_reduce(host, op=op, group=self.pg, async_op=True)
             self.handles.append((h, (view, host)))
-            self.launched += 1
-            bk["pending"] = -1
             return
         if self.launch_stream is not None:
             # the bucket's gradients come from two streams (wgrad on the side stream, BN/bias pieces on the main one):
@@ -128,8 +165,31 @@ class GradReducer(object):
         else:
             h = dist.all_reduce(view, op=op, group=self.pg, async_op=True)
         self.handles.append((h, view))
-        self.launched += 1
-        bk["pending"] = -1
+
+    def _launch_and_update(self, bk, view, op):
+        """Bucket -> finishing stream: wait for both producing streams, all-reduce, wait for it, optimizer update of the slice.
+        Neither the main stream nor the weight-gradient stream waits for anything here."""
+        fin = self.finishing_stream()
+        ev = torch.cuda.Event()
+        ev.record()                                 # main stream: BN / bias gradients and everything that READS these parameters
+        fin.wait_event(ev)
+        if self.launch_stream is not None:
+            ev2 = torch.cuda.Event()
+            ev2.record(self.launch_stream)          # weight-gradient stream: the bucket's last wgrad launch is already enqueued
+            fin.wait_event(ev2)
+        if not self.local:
+            with torch.cuda.stream(fin):
+                if self.stage_host:
+                    host = view.cpu()               # gloo: host-staged and host-blocking (tests only)
+                    dist.all_reduce(host, op=op, group=self.pg)
+                    view.copy_(host.mul_(1.0 / self.world))
+                else:
+                    h = dist.all_reduce(view, op=op, group=self.pg, async_op=True)
+                    h.wait()                        # the FINISHING stream waits for RCCL's stream; the host does not block
+                    if not self.use_avg:
+                        view.mul_(1.0 / self.world)
+        self.on_bucket(bk["start"], bk["end"], fin.cuda_stream)
+        self.updated += 1
 
     def finish(self):
         # parameters that received no gradient this step (unused heads) still have to be reduced so
@@ -137,8 +197,10 @@ class GradReducer(object):
         for bk in self.buckets:
             if bk["pending"] >= 0:
                 self._launch(bk)
-        if self.measure and torch.cuda.is_available():
-            # bench.py: GPU time the launch stream spends in the waits below = all-reduce time NOT hidden behind backward
+        timed = self.measure and torch.cuda.is_available() and self.arena.device.type == "cuda"
+        if timed:
+            # bench.py: GPU time the launch stream spends in the waits below = all-reduce (and, with per-bucket updates, the last
+            # bucket's update) time NOT hidden behind backward
             if self._ev is None:
                 self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self._ev[0].record()
@@ -149,13 +211,16 @@ class GradReducer(object):
                 view.copy_(host.mul_(1.0 / self.world))
             elif not self.use_avg:
                 view.mul_(1.0 / self.world)
-        if self.measure and self._ev is not None:
+        if self._finish_stream is not None and self.updated:
+            torch.cuda.current_stream().wait_stream(self._finish_stream)      # join: every bucket's update is complete
+        if timed:
             self._ev[1].record()
         self.handles = []
 
     def exposed_ms(self):
-        """GPU time between the end of backward on the launch stream and the completion of the last collective, for the most
-        recent step (needs ``measure = True`` before that step and a device synchronisation after it)."""
+        """GPU time between the end of backward on the launch stream and the completion of the last collective (and of the last
+        bucket's optimizer update when the step runs them per bucket), for the most recent step (needs ``measure = True``
+        before that step and a device synchronisation after it)."""
         if self._ev is None:
             return None
         return float(self._ev[0].elapsed_time(self._ev[1]))

@@ -38,6 +38,8 @@ class Ctx(object):
         self.wt_ready = None     # event: the transposed weight copies (made on the side stream) are complete
         self.bnb = {}            # id(BN output Act) -> per-tile backward statistics produced by the launch that completed its gradient
         self.fwd_side_join = False   # forward work is in flight on the side stream (Engine.det_pyramid): join before it is consumed
+        self.schedule = None     # bucket schedule of this backward pass: the data-parallel GradReducer, or its process-group-free
+                                 # twin when one GPU runs per-bucket optimizer updates (Engine.run_backward)
         self.lazy_res = {}       # id(Act) -> (dz, mask bits): shortcut gradient dz * (z > 0) NOT materialised; the convolution whose
                                  # input gradient completes that Act adds it in its epilogue (Engine.defer_shortcut_grad)
 
@@ -247,8 +249,8 @@ class Engine(object):
     def _grad_done(self, ctx, p):
         n = ctx.uses.get(id(p), 0) - 1
         ctx.uses[id(p)] = n
-        if n == 0 and self.m._reducer is not None:
-            self.m._reducer.param_ready(p)
+        if n == 0 and ctx.schedule is not None:
+            ctx.schedule.param_ready(p)
 
     # ------------------------------------------------------------------ ops
     def _bn_fin(self, bn):
@@ -894,17 +896,21 @@ class Engine(object):
         return cls_all, reg_all
 
     # ------------------------------------------------------------------ backward
-    def run_backward(self, ctx, out_grads):
+    def run_backward(self, ctx, out_grads, schedule=None, on_bucket=None):
+        """``schedule``: bucket schedule to notify as parameter gradients complete (default: the model's data-parallel reducer);
+        ``on_bucket``: the optimizer's slice update, run behind each bucket (ddp.GradReducer) — only a step that owns its optimizer
+        passes one (replay.py); ``loss.backward()`` leaves the update to ``optimizer.step()``."""
         m = self.m
         ctx.out_grads = out_grads
         ops.check_device(m._arena.flat)
         m._arena.ensure_grads()
         dev = m._arena.flat.device
         side = self.side_stream(dev)
-        if m._reducer is not None:
-            m._reducer.launch_stream = side
-            m._reducer.pre_launch = (lambda: self.flush_side(ctx, dev)) if side is not None else None
-            gpu_op(m._reducer.begin)
+        sched = ctx.schedule = schedule if schedule is not None else m._reducer
+        if sched is not None:
+            sched.launch_stream = side
+            sched.pre_launch = (lambda: self.flush_side(ctx, dev)) if side is not None else None
+            gpu_op(sched.begin, on_bucket)
         if ctx.wt_ready is not None:
             gpu_op(torch.cuda.current_stream(dev).wait_event, ctx.wt_ready)
             ctx.wt_ready = None
@@ -920,6 +926,7 @@ class Engine(object):
         ctx.side_keep = []
         ctx.wt.clear()
         ctx.wt_buf = None
-        if m._reducer is not None:
-            m._reducer.pre_launch = None
-            gpu_op(m._reducer.finish)
+        if sched is not None:
+            sched.pre_launch = None
+            gpu_op(sched.finish)
+        ctx.schedule = None

@@ -20,7 +20,9 @@ import warnings
 import torch
 
 from . import ops
-from ._lib import call
+import ctypes
+
+from ._lib import call, call_raw
 
 _NH = 16       # floats in the device hyper vector (9 used)
 
@@ -123,6 +125,29 @@ class FusedAdam(torch.optim.Optimizer):
             call("mpn_adam_step_dev", ops.ptr(ar.flat[s:e]), ops.ptr(ar.grad_flat[s:e]), ops.ptr(self._m[s:e]), ops.ptr(self._v[s:e]),
                  e - s, ops.ptr(self._hyper), ops.stream_ptr())
         return loss
+
+    # ------------------------------------------------------------------ the update, bucket by bucket (ddp.GradReducer.on_bucket)
+    @torch.no_grad()
+    def begin_bucketed(self):
+        """First half of ``step()`` for a step that updates bucket by bucket while backward still runs: bind, upload changed
+        hyper-parameters, advance the device step count / bias corrections on the CURRENT stream (every bucket's update is ordered
+        after it through the bucket's readiness event).  The second half is ``update_slice`` per bucket."""
+        ar = self._bind()
+        ops.check_device(ar.flat)
+        ar.ensure_grads()
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_hyper()
+        call("mpn_adam_advance", ops.ptr(self._hyper), ops.stream_ptr())
+        base = (ar.flat.data_ptr(), ar.grad_flat.data_ptr(), self._m.data_ptr(), self._v.data_ptr())
+        hyper = self._hyper.data_ptr()
+
+        def update_slice(start, end, raw_stream):
+            # same kernel, same hyper vector, element-wise: the parameters equal the single-launch step's bit for bit
+            o = 4 * start
+            call_raw("mpn_adam_step_dev", ctypes.c_void_p(base[0] + o), ctypes.c_void_p(base[1] + o), ctypes.c_void_p(base[2] + o),
+                     ctypes.c_void_p(base[3] + o), end - start, ctypes.c_void_p(hyper), ctypes.c_void_p(raw_stream))
+        update_slice.keep = (ar.flat, ar.grad_flat, self._m, self._v, self._hyper)
+        return update_slice
 
     # ------------------------------------------------------------------ checkpointing (torch.optim.Adam layout)
     def _group_params(self):

@@ -49,6 +49,13 @@ class ReplayedTrainStep(object):
         self.opt = optimizer
         # heat-map loss + gradients in one launch over the internal tensors (MPN_FUSED_MSE=0: the API path's kernel chain)
         self.fused_mse = (os.environ.get("MPN_FUSED_MSE", "1") != "0") if fused_mse is None else bool(fused_mse)
+        # Adam bucket by bucket behind each bucket's all-reduce (ddp.GradReducer's finishing stream) instead of one launch after
+        # backward.  MPN_BUCKET_ADAM: unset = when a data-parallel reducer is attached (it removes the exposed last collective + the
+        # whole-arena Adam from the N > 1 critical path); 1 = also on one GPU through the group-free schedule (measured +0.1 ms at the
+        # headline size: the update competes with backward for HBM instead of following it, profiles/r06_bucket_adam_ab.txt); 0 = never
+        mode = os.environ.get("MPN_BUCKET_ADAM", "")
+        self.bucket_mode = mode if mode in ("0", "1") else "auto"
+        self._can_bucket = hasattr(optimizer, "begin_bucketed")
         self.eager_steps = max(1, int(eager_steps))       # steps that fill host-side caches (anchors, transpose table, Adam state)
         # One recording per input signature, each owning a MemPool with a whole step's activations (GBs at the headline size).  The
         # reference's bbox_collater pads annotations to the per-batch maximum, so detection training sees a new signature for nearly
@@ -113,9 +120,29 @@ class ReplayedTrainStep(object):
                 grads[slot] = g
         if want_det:     # d(total)/d(cls loss) = d(total)/d(reg loss) = 1 (posenet.py:417-421)
             grads["cls"], grads["reg"] = losses.focal_backward_raw(fsaved, ones)
-        eng.run_backward(ctx, grads)
-        self.opt.step()
+        if self.bucketed_update:
+            # the optimizer update of a bucket runs as soon as the bucket's gradients (and, data-parallel, its all-reduce) are
+            # complete, on the reducer's finishing stream under the rest of backward; one GPU: the same schedule without a group
+            sched = m._reducer if m._reducer is not None else self._local_schedule()
+            eng.run_backward(ctx, grads, schedule=sched, on_bucket=self.opt.begin_bucketed())
+        else:
+            eng.run_backward(ctx, grads)
+            self.opt.step()
         return logv, want_kp, want_det
+
+    @property
+    def bucketed_update(self):
+        if not self._can_bucket or self.bucket_mode == "0":
+            return False
+        return self.bucket_mode == "1" or self.model._reducer is not None
+
+    def _local_schedule(self):
+        from .ddp import GradReducer
+        ar = self.model._arena
+        sc = getattr(self, "_local", None)
+        if sc is None or sc.arena is not ar:
+            sc = self._local = GradReducer(ar, local=True, bucket_mb=float(os.environ.get("MPN_BUCKET_MB", "32")))
+        return sc
 
     def _ones(self, dev):
         t = getattr(self, "_ones_t", None)
@@ -137,7 +164,7 @@ class ReplayedTrainStep(object):
         m = self.model
         ar = m._arena
         return (id(ar), id(ar.grad_flat), tuple(p.requires_grad for p in ar.params), tuple(b.training for b in m._bns),
-                m.compute_dtype, id(m._reducer), m._engine.overlap_wgrad, m._engine.fork_every, id(self.opt._m))
+                m.compute_dtype, id(m._reducer), m._engine.overlap_wgrad, m._engine.fork_every, id(self.opt._m), self.bucketed_update)
 
     # ------------------------------------------------------------------ call
     def __call__(self, inputs, gts):

@@ -79,6 +79,10 @@ def main():
             res[mode + "_loss"] = np.array(losses)
             if stepper is not None:
                 res["replays"] = stepper.replays
+                # round 6: the recorded data-parallel step updates bucket by bucket behind each all-reduce (finishing stream)
+                res["bucket_updates"] = m._reducer.updated
+                res["buckets"] = len(m._reducer.buckets)
+                res["bucketed"] = int(stepper.bucketed_update)
         np.savez(os.path.join(os.environ["MPN_DDP_OUT"], "rank%d.npz" % rank), backend=backend, **res)
         dist.barrier()
         dist.destroy_process_group()

@@ -79,6 +79,31 @@ def _worker(rank, world, port, ret):
         assert red.launched == len(red.buckets)
         s, e = runs[0]
         assert torch.allclose(ar.grad_flat[s:e], pattern[s:e] * mean_scale, rtol=1e-6, atol=1e-7)
+        # (4b) per-bucket optimizer update (round 6): every bucket is updated exactly once, right behind ITS all-reduce, with the
+        # averaged gradient; the parameters equal "reduce everything, then one update over the arena"
+        ar.grad_flat.copy_(pattern * (rank + 1))
+        start = ar.flat.clone()
+        seen = []
+
+        def sgd(s_, e_, stream):
+            seen.append((s_, e_))
+            ar.flat[s_:e_] -= 0.5 * ar.grad_flat[s_:e_]
+        red.begin(sgd)
+        for p in trainable[: len(trainable) // 2]:
+            red.param_ready(p)
+        n_mid = len(seen)
+        assert 0 < n_mid < len(red.buckets), "updates must start while 'backward' is still producing gradients"
+        red.finish()
+        assert sorted(seen) == sorted((b["start"], b["end"]) for b in red.buckets) and red.updated == len(red.buckets)
+        want = start.clone()
+        for s_, e_ in runs:
+            want[s_:e_] -= 0.5 * pattern[s_:e_] * mean_scale
+        assert torch.allclose(ar.flat, want, rtol=1e-6, atol=1e-7)
+        assert torch.equal(ar.flat[frozen_off: frozen_off + 8], start[frozen_off: frozen_off + 8])
+        red.begin()                                   # a plain backward afterwards must not update anything
+        assert red.on_bucket is None
+        red.finish()
+        ar.flat.copy_(start)
         # (5) equal-shard equivalence on a real differentiable function of the arena
         x = torch.linspace(-1, 1, 8 * 16).view(8, 16)
         w = ar.flat[:16].clone().requires_grad_(True)

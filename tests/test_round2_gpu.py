@@ -319,6 +319,9 @@ def test_two_rank_recorded_step_equals_the_eager_data_parallel_step():
     res = [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(2)]
     for r in range(2):
         assert int(res[r]["replays"]) == 2
+        # round 6: the recorded step's Adam ran bucket by bucket behind each all-reduce, the eager job's as one
+        # launch after backward — and the parameters still agree bit for bit
+        assert int(res[r]["bucketed"]) == 1 and int(res[r]["bucket_updates"]) == int(res[r]["buckets"]) >= 2
         assert np.array_equal(res[r]["eager_params"], res[r]["replay_params"]), "rank %d: recorded step diverged from the eager step" % r
         assert np.allclose(res[r]["eager_loss"], res[r]["replay_loss"], rtol=2e-6, atol=0)      # heat-map loss: f32 summation order only
     assert np.array_equal(res[0]["replay_params"], res[1]["replay_params"]), "ranks hold different parameters after four steps"

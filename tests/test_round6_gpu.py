@@ -1,0 +1,170 @@
+"""Round 6 GPU tests: the N > 1 step is tail-free and fail-safe before it is first measured.
+
+  * per-bucket Adam behind each bucket's gradients / all-reduce on the finishing stream == the single-launch Adam, bit for bit
+    (one GPU, local schedule; two ranks over gloo in tests/test_round2_gpu.py's replay worker, which now asserts the count);
+  * `bench.py --gpus 8 --shared-device-test`: eight ranks through spawn -> rendezvous -> recorded data-parallel step -> ONE line;
+  * `--rccl-channels` / environment echoed in the dist block; a rank that cannot rendezvous exits 3 with a diagnosis.
+"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT, report
+
+pytestmark = pytest.mark.gpu
+
+
+def _clean_env():
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def _train_setup(layers=50, B=4, S=128, dtype=torch.bfloat16):
+    from multiposenet.pytorch_amd import synthetic as weightgen
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    torch.manual_seed(0)
+    m = poseNet(layers, compute_dtype=dtype).cuda()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = weightgen.gen_state_dict(shapes, seed=0, flavour="he", skip_prefixes=("prn.",))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    for p in m.prn.parameters():
+        p.requires_grad = False
+    m.train()
+    img = torch.from_numpy(weightgen.gen_images(7, B, S, S)).cuda()
+    heat, wgt = (torch.from_numpy(a).cuda() for a in weightgen.gen_keypoint_gt(8, B, S // 4, S // 4))
+    anno = torch.from_numpy(weightgen.gen_boxes_gt(9, B, S)).cuda()
+    return m, [[img, "train_both"]], ["train_both", heat, wgt, anno]
+
+
+@pytest.mark.parametrize("subnet", ["train_both", "keypoint_subnet"])
+def test_per_bucket_adam_equals_the_single_launch_adam_bit_for_bit(subnet, monkeypatch):
+    """Recorded step with MPN_BUCKET_ADAM=1 (Adam per ~8 MB bucket on the finishing stream while backward still runs) vs =0 (one
+    launch over the arena after backward), five optimizer steps with batch-statistics BatchNorm: parameters, both moments and the
+    step count identical bit for bit; every bucket updated exactly once per step, the unused detection head's buckets (keypoint
+    step) by finish().  Replaces trainer.py:259's optimizer.step() for the step that owns its optimizer."""
+    import copy
+    from multiposenet.pytorch_amd.optim import FusedAdam
+    from multiposenet.pytorch_amd.replay import ReplayedTrainStep
+    monkeypatch.setenv("MPN_BUCKET_MB", "8")
+    m, inputs, gts = _train_setup()
+    if subnet == "keypoint_subnet":
+        inputs = [[inputs[0][0], subnet]]
+        gts = [subnet, gts[1], gts[2]]
+    start = copy.deepcopy(m.state_dict())
+    start_flat = m._arena.flat.detach().cpu().numpy().copy()
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MPN_BUCKET_ADAM", mode)
+        m.load_state_dict(start)
+        opt = FusedAdam(m, lr=1e-3, weight_decay=1e-4)
+        stepper = ReplayedTrainStep(m, opt)
+        assert stepper.bucketed_update == (mode == "1")
+        losses = [float(stepper(inputs, gts)[0]) for _ in range(5)]
+        torch.cuda.synchronize()
+        res[mode] = (m._arena.flat.detach().cpu().numpy().copy(), opt._m.cpu().numpy().copy(), opt._v.cpu().numpy().copy(), opt.step_count(), losses)
+        if mode == "1":
+            sc = stepper._local
+            assert sc.local and len(sc.buckets) >= 4 and sc.updated == len(sc.buckets) == sc.launched, (sc.updated, len(sc.buckets))
+            assert stepper.replays >= 3
+            nb = len(sc.buckets)
+    a, b = res["0"], res["1"]
+    assert a[3] == b[3] == 5
+    assert np.array_equal(a[0], b[0]), "parameters differ between per-bucket and single-launch Adam"
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), "Adam moments differ"
+    assert a[4] == b[4] and all(np.isfinite(a[4]))
+    assert np.abs(a[0] - start_flat).max() > 1e-4, "parameters never moved"
+    report("per-bucket Adam (%s, %d buckets of <= 8 MB, 5 recorded steps) == single-launch Adam: parameters / moments bit-identical; loss %.4f -> %.4f"
+           % (subnet, nb, a[4][0], a[4][-1]))
+
+
+def test_eager_backward_after_a_recorded_step_does_not_update_in_backward():
+    """The per-bucket update is installed by the recorded step's begin(on_bucket) and cleared by the next plain backward: an eager
+    loss.backward() + optimizer.step() in between applies exactly ONE update (bench.py runs instrumented eager steps on the same
+    model and reducer after the timed region)."""
+    from multiposenet.pytorch_amd.optim import FusedAdam
+    from multiposenet.pytorch_amd.replay import ReplayedTrainStep
+    from multiposenet.pytorch_amd.training.batch_processor import train_step
+    m, inputs, gts = _train_setup(B=2, S=96, dtype=torch.float32)
+    m.freeze_bn()
+    opt = FusedAdam(m, lr=1e-3)
+    stepper = ReplayedTrainStep(m, opt)
+    for _ in range(3):
+        stepper(inputs, gts)
+    torch.cuda.synchronize()
+    t0 = opt.step_count()
+    before = m._arena.flat.detach().clone()
+    train_step(m, opt, inputs, gts)
+    torch.cuda.synchronize()
+    assert opt.step_count() == t0 + 1
+    # Adam's first-order bound: one update moves a parameter by at most ~lr (bias-corrected |m/sqrt(v)| <= ~1 after a few steps, generous 3x)
+    moved = (m._arena.flat.detach() - before).abs().max().item()
+    assert 0 < moved <= 3e-3, moved
+    stepper(inputs, gts)
+    torch.cuda.synchronize()
+    assert opt.step_count() == t0 + 2
+
+
+def test_bench_spawn_path_runs_eight_ranks_to_one_json_line():
+    """The driver's 8-GPU command, on one device: `bench.py --gpus 8 --shared-device-test` -> spawn_ranks -> torch.distributed.run ->
+    rendezvous of EIGHT ranks on 127.0.0.1 (with the init timeout and the probe collective) -> ddp.attach -> recorded data-parallel
+    step with per-bucket updates -> barrier / max over ranks -> ONE JSON line with eight per_rank_ms.  gloo, every rank on device 0,
+    labelled not_a_measurement (RCCL refuses two ranks on one GPU).  Replaces datasets/data_parallel.py:16-87 / trainer.py:170."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--shared-device-test",
+           "--layers", "50", "--size", "256", "--batch", "2", "--no-kernel-events"]
+    t0 = time.time()
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=_clean_env(), cwd=ROOT)
+    assert res.returncode == 0, "bench.py --gpus 8 failed (rc %d):\n%s" % (res.returncode, res.stderr[-3000:])
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, "stdout must carry exactly one line, got %d:\n%s" % (len(lines), res.stdout[-2000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 2 and out["not_a_measurement"] is True and out["config"]["global_batch"] == 16
+    d = out["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 8 and len(d["per_rank_ms"]) == 8 and all(v > 0 for v in d["per_rank_ms"])
+    assert d["collectives_per_step"] == d["buckets"] == d["optimizer_updates_behind_buckets"] >= 1
+    assert d["rccl_channels"] == "library default" and d["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert "cpu_baseline" not in out and np.isfinite(out["last_step_log"]["total_loss"])
+    report("bench.py --gpus 8 --shared-device-test: 8 ranks -> one JSON line in %.0f s (per-rank ms %s; not a measurement)" % (time.time() - t0, d["per_rank_ms"]))
+
+
+def test_force_dist_line_echoes_channels_and_runs_updates_behind_buckets():
+    """One rank over RCCL with --rccl-channels 8: NCCL_MIN/MAX_NCHANNELS set before init and echoed; the per-bucket updates ran."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--rccl-channels", "8", "--steps", "4", "--warmup", "2", "--layers", "50",
+           "--size", "256", "--batch", "8", "--no-kernel-events", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_clean_env(), cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')][0])
+    d = out["dist"]
+    assert d["rccl_channels"] == 8 and d["env"]["NCCL_MIN_NCHANNELS"] == "8" and d["env"]["NCCL_MAX_NCHANNELS"] == "8"
+    assert d["backend"] == "nccl" and d["optimizer_updates_behind_buckets"] == d["buckets"] == d["collectives_per_step"]
+    assert d["allreduce_ms_exposed"][0] is not None and 0.0 <= d["allreduce_ms_exposed"][0] < out["ms_per_step"]
+    report("bench.py --force-dist --rccl-channels 8: %d buckets updated behind their collectives, exposed tail %.3f ms of %.2f ms/step"
+           % (d["buckets"], d["allreduce_ms_exposed"][0], out["ms_per_step"]))
+
+
+def test_rank_that_cannot_rendezvous_exits_3_with_a_diagnosis():
+    """A lone rank of a 2-rank job (its peer never starts) must not hold the GPU lease for torch's default ten minutes: with
+    --init-timeout 15 it exits with status 3 and ONE diagnostic line naming the rendezvous, and prints no JSON."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(_clean_env(), RANK="1", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shared-device-test", "--init-timeout", "15", "--layers", "50",
+           "--size", "128", "--batch", "2", "--steps", "1", "--warmup", "0"]
+    t0 = time.time()
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    dt = time.time() - t0
+    assert res.returncode == 3, (res.returncode, res.stderr[-1500:])
+    assert "could not join the process group" in res.stderr and "MASTER_PORT=%d" % port in res.stderr
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert dt < 200, dt
+    report("lone rank of a 2-rank job: exit 3 after %.0f s with: %s" % (dt, [ln for ln in res.stderr.splitlines() if "could not join" in ln][0][:160]))
