@@ -424,10 +424,14 @@ int mpn_gt_heatmaps(const double* joints, const int32_t* num_people, int B, int 
  * counted over joints 0..J-1 in that order; with refine != 0 the position/score come from the bicubically
  * (cv2 INTER_CUBIC) `upsamp`-times up-sampled 5x5 patch around the cell, else from the cell itself
  * ((c + 0.5)*upsamp - 0.5, rounded half to even).  counts[b][j] = number of peaks found (only the first
- * `cap` are stored).
+ * `cap` are stored).  workspace: mpn_heatmap_peaks_workspace_bytes(B, J, H, W, cap) bytes of device scratch (one flag bit
+ * per cell, the device-wide peak list of the refinement launch); contents need no initialisation.  Three launches: flags
+ * (coalesced in channels-last [sJ == 1, sX == J] and planar [sX == 1] layouts), per-plane compaction, refinement.
  * -------------------------------------------------------------------------------------------*/
+int64_t mpn_heatmap_peaks_workspace_bytes(int B, int J, int H, int W, int cap);
 int mpn_heatmap_peaks(const float* heat, int64_t sB, int64_t sJ, int64_t sY, int64_t sX, int B, int J, int H, int W,
-                      float thre1, double upsamp, int refine, double* peaks, int32_t* counts, int cap, void* stream);
+                      float thre1, double upsamp, int refine, double* peaks, int32_t* counts, int cap, void* workspace,
+                      void* stream);
 
 /* cv2.resize for float32 images / heat-map stacks (evaluate/tester.py:67,213,296-299): src element (y, x, c) at
  * src[y*sY + x*sX + c*sC]; dst dense [Hd][Wd][C]; cubic != 0 -> INTER_CUBIC, else INTER_LINEAR (OpenCV's coordinate rule

@@ -71,7 +71,8 @@ _PW = ctypes.POINTER(WgradParams)
 # against the header and against the exported dynamic symbols).
 SIGNATURES = {
     "mpn_gt_heatmaps": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, ctypes.c_double, ctypes.c_double, _vp]),
-    "mpn_heatmap_peaks": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _f, ctypes.c_double, _i, _vp, _vp, _i, _vp]),
+    "mpn_heatmap_peaks_workspace_bytes": (_i64, [_i, _i, _i, _i, _i]),
+    "mpn_heatmap_peaks": (_i, [_vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _f, ctypes.c_double, _i, _vp, _vp, _i, _vp, _vp]),
     "mpn_resize": (_i, [_vp, _i64, _i64, _i64, _i, _i, _i, _vp, _i, _i, _i, ctypes.c_double, ctypes.c_double, _vp]),
     "mpn_prn_build_maps": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, ctypes.c_double, _vp, _vp, _vp, _vp, _vp]),
     "mpn_prn_scores": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -158,7 +159,7 @@ SIGNATURES = {
 
 # entry points that return a count, not a status
 _COUNT_FUNCS = {"mpn_conv_stats_tiles", "mpn_conv_tile_rows", "mpn_conv_shared_tile", "mpn_conv_wgrad_chunks", "mpn_conv_wgrad_seg_plan", "mpn_conv_wgrad_kernel_id", "mpn_bn_bwd_chunks", "mpn_channel_sum_chunks",
-                "mpn_mse_chunks", "mpn_mse_train_blocks", "mpn_focal_blocks", "mpn_bce_chunks", "mpn_nms_workspace_bytes", "mpn_nms_batched_workspace_bytes", "mpn_version"}
+                "mpn_mse_chunks", "mpn_mse_train_blocks", "mpn_focal_blocks", "mpn_bce_chunks", "mpn_nms_workspace_bytes", "mpn_nms_batched_workspace_bytes", "mpn_heatmap_peaks_workspace_bytes", "mpn_version"}
 
 _lib = None
 

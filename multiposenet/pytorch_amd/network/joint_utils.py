@@ -27,8 +27,9 @@ def _peaks_device(heat_bjhw, thre1, upsamp, refine, cap=DEFAULT_CAP):
     sB, sJ, sY, sX = heat_bjhw.stride()
     peaks = torch.empty((B, J, cap, 4), dtype=torch.float64, device=heat_bjhw.device)
     counts = torch.empty((B, J), dtype=torch.int32, device=heat_bjhw.device)
+    ws = ops.workspace(call("mpn_heatmap_peaks_workspace_bytes", B, J, H, W, cap), heat_bjhw.device, slot=8)
     call("mpn_heatmap_peaks", ops.ptr(heat_bjhw), sB, sJ, sY, sX, B, J, H, W, float(thre1), float(upsamp), 1 if refine else 0,
-         ops.ptr(peaks), ops.ptr(counts), cap, ops.stream_ptr())
+         ops.ptr(peaks), ops.ptr(counts), cap, ops.ptr(ws), ops.stream_ptr())
     return peaks, counts
 
 

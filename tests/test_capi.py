@@ -125,6 +125,8 @@ def test_entry_points_reject_bad_arguments_without_touching_the_gpu():
     assert L.mpn_bn_bwd_reduce(one, nul, one, one, one, nul, nul, one, 1, 16, 32, 32, 1, 1, nul) == BAD   # relu without z or mask coefficients
     assert L.mpn_gt_heatmaps(nul, one, 1, 1, one, 4, 4, 4.0, 7.0, nul) == BAD
     assert L.mpn_gt_heatmaps(one, one, 1, 1, one, 4, 4, 0.0, 7.0, nul) == BAD
-    assert L.mpn_heatmap_peaks(one, 0, 0, 0, 0, 1, 18, 0, 8, 0.1, 4.0, 1, one, one, 16, nul) == BAD
-    assert L.mpn_heatmap_peaks(one, 0, 0, 0, 0, 1, 18, 8, 8, 0.1, 4.0, 1, one, one, 0, nul) == BAD       # cap == 0
+    assert L.mpn_heatmap_peaks(one, 0, 0, 0, 0, 1, 18, 0, 8, 0.1, 4.0, 1, one, one, 16, one, nul) == BAD
+    assert L.mpn_heatmap_peaks(one, 0, 0, 0, 0, 1, 18, 8, 8, 0.1, 4.0, 1, one, one, 0, one, nul) == BAD       # cap == 0
+    assert L.mpn_heatmap_peaks(one, 0, 0, 0, 0, 1, 18, 8, 8, 0.1, 4.0, 1, one, one, 16, nul, nul) == BAD     # no workspace
+    assert L.mpn_heatmap_peaks_workspace_bytes(64, 18, 160, 160, 256) == (64 * 18 * 160 * 3 * 8 + 255) // 256 * 256 + 64 * 18 * 256 * 4 + 256
     assert L.mpn_nms(nul, 4, 0.5, 0, one, one, one, nul) != 0

@@ -83,3 +83,32 @@ def test_edge_cases():
     assert [len(p) for p in full] == [63] * 18 and full[17][-1][3] == 63 * 18 - 1
     with pytest.raises(MpnError):
         ju.NMS(PARAM, flat.cpu(), 4.0)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 33, 70), (1, 18, 160, 160), (3, 2, 7, 129)])
+def test_layouts_and_dense_noise_vs_oracle(shape):
+    """Round 6 kernels (flags -> per-plane compaction -> refinement over a device-wide list): the channels-last fast path, the
+    planar path and a strided view (generic path) give the same peaks as the oracle's restatement of joint_utils.py:61-138 on
+    NOISE maps (~15 % of the cells are peaks: hundreds to thousands per plane, several 256-word chunks per plane, widths that are not
+    multiples of 64), with and without refinement — coordinates, ids and float32 scores exactly."""
+    ju = _ju()
+    B, J, H, W = shape
+    rng = np.random.RandomState(B * 1000 + W)
+    heat = rng.rand(B, J, H, W).astype(np.float32)
+    heat[0, 0, :3, :] = 0.99                                            # a plateau: every cell of it is a peak
+    thre = 0.97 if H * W > 10000 else 0.3                               # (the oracle refines peak by peak in Python)
+    t = torch.from_numpy(heat).cuda()
+    big = torch.zeros((B, J + 1, H + 2, W + 3), device="cuda")
+    big[:, 1:, 1:-1, 2:-1] = t
+    views = {"planar": t, "channels_last": t.contiguous(memory_format=torch.channels_last), "strided": big[:, 1:, 1:-1, 2:-1]}
+    if J > 1:
+        assert views["channels_last"].stride(1) == 1 and views["channels_last"].stride(3) == J
+    for refine in (False, True):
+        ref = [jo.nms_peaks(thre, np.ascontiguousarray(heat[b].transpose(1, 2, 0)), 4.0, refine=refine) for b in range(B)]
+        for name, v in views.items():
+            got = ju.NMS_batch({"thre1": thre}, v, 4.0, bool_refine_center=refine)
+            for b in range(B):
+                assert [len(p) for p in got[b]] == [len(p) for p in ref[b]], (name, refine, b)
+                g, r = np.concatenate(got[b]), np.concatenate(ref[b])
+                assert np.array_equal(g, r), (name, refine, b, float(np.abs(g - r).max()))
+    assert sum(len(p) for p in ref[0]) > (0.02 if thre > 0.9 else 0.1) * J * H * W
