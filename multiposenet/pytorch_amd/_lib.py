@@ -154,12 +154,18 @@ SIGNATURES = {
     "mpn_fill_f32": (_i, [_vp, _f, _i64, _vp]),
     "mpn_copy_bytes": (_i, [_vp, _vp, _i64, _vp]),
     "mpn_step_log": (_i, [_vp, _vp, _vp, _vp]),
+    "mpn_conv2cls_comb_elems": (_i64, [_i, _i]),
+    "mpn_conv2cls_combine": (_i, [_vp, _vp, _i, _i, _vp]),
+    "mpn_conv2cls_expand": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mpn_conv2cls_pool": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mpn_conv2cls_tapsum": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mpn_conv2cls_fold": (_i, [_vp, _vp, _i, _i, _vp]),
     "mpn_version": (ctypes.c_char_p, []),
 }
 
 # entry points that return a count, not a status
 _COUNT_FUNCS = {"mpn_conv_stats_tiles", "mpn_conv_tile_rows", "mpn_conv_shared_tile", "mpn_conv_wgrad_chunks", "mpn_conv_wgrad_seg_plan", "mpn_conv_wgrad_kernel_id", "mpn_bn_bwd_chunks", "mpn_channel_sum_chunks",
-                "mpn_mse_chunks", "mpn_mse_train_blocks", "mpn_focal_blocks", "mpn_bce_chunks", "mpn_nms_workspace_bytes", "mpn_nms_batched_workspace_bytes", "mpn_heatmap_peaks_workspace_bytes", "mpn_version"}
+                "mpn_mse_chunks", "mpn_mse_train_blocks", "mpn_focal_blocks", "mpn_bce_chunks", "mpn_nms_workspace_bytes", "mpn_nms_batched_workspace_bytes", "mpn_heatmap_peaks_workspace_bytes", "mpn_conv2cls_comb_elems", "mpn_version"}
 
 _lib = None
 

@@ -1034,8 +1034,12 @@ int launch_conv_k(const MpnConvParams& p, int tc, long grid, int dbg, hipStream_
             return mpn_launch_status();
         }
     }
-    if (tc == 256) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, kTP, OUTF32, GENERAL, EXT>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
-    else if (tc == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, kTP, OUTF32, GENERAL, EXT>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+    if (tc == 256) {
+        // pick_tc() never chooses the 256-row tile for f32 (the exact-fp32 MFMA loop is matrix-pipe bound: three 128-row workgroups per
+        // CU beat two 256-row ones, profiles/r05_cfg2_tile_rule_sweep.txt): no <float, 256, ...> instantiation exists
+        if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((conv_igemm_kernel<T, 256, kTP, OUTF32, GENERAL, EXT>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
+        else return MPN_E_UNSUPPORTED;
+    } else if (tc == 128) hipLaunchKernelGGL((conv_igemm_kernel<T, 128, kTP, OUTF32, GENERAL, EXT>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
     else if (tc == 64) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, kTP, OUTF32, GENERAL, EXT>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
     else hipLaunchKernelGGL((conv_igemm_kernel<T, 32, kTP, OUTF32, GENERAL, EXT>), dim3((unsigned)grid), dim3(256), 0, st, p, dbg);
     return mpn_launch_status();

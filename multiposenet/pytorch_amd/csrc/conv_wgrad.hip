@@ -795,7 +795,7 @@ inline void wgrad_tiles(const MpnWgradParams& p, int& tm, int& tn) {
     // per CU the transpose reads are no longer hidden and the slice count (partial-sum traffic) doubles.  Kept behind
     // MPN_WGRAD_TM256_MIN_STEPS (minimum k-steps per workgroup) for experiments, off by default.
     static const long min_steps = mpn_tune("MPN_WGRAD_TM256_MIN_STEPS", 1L << 40);
-    if (p.Cin >= 256 && tn == 128) {
+    if (p.dtype != MPN_F32 && p.Cin >= 256 && tn == 128) {        // (the f32 ring kernel has no 256-row instantiation)
         const long tiles = (long)((p.Cin + 255) / 256) * ((p.Cout + 127) / 128) * p.R * p.S;
         const long chunks = (kWgradTarget + tiles - 1) / tiles;
         const long P = (long)p.B * p.Ho * p.Wo;
@@ -888,13 +888,24 @@ extern "C" int mpn_conv_wgrad_seg_plan(MpnWgradParams* p) {
     const int want = mpn_conv_wgrad_chunks(p);
     if (want < 1) return want;
     const long P = wgrad_total_pixels(*p);
-    long cp = (P + want - 1) / want;
-    cp = ((cp + 31) / 32) * 32;
+    // Every level rounds its slice count up, so `want` slices of the whole pyramid become more (14 -> 17 on p3..p7 at 480x480: 612
+    // workgroups on the 512 slots mpn_conv_wgrad_chunks aimed at).  Round 6 measured the obvious remedy — lengthen the slices until the
+    // total fits `want` again, the never-one-more rule of the single-tensor launches — in the step: 36.09 / 36.10 -> 36.24 / 36.29 ms
+    // (profiles/r06_small_items_ab.txt): under the two-stream schedule the tail round is filled by the other stream and the longer
+    // slices only lengthen the launch.  Off; MPN_WGRAD_SEG_FIT=1 in the experiments build.
+    static const bool fit = mpn_tune("MPN_WGRAD_SEG_FIT", 0) != 0;
+    long cp = 0;
     int c = 0;
-    for (int l = 0; l < p->nseg; ++l) {
-        p->seg_chunk0[l] = c;
-        const long pl = (long)p->B * p->seg_H[l] * p->seg_W[l];
-        c += (int)((pl + cp - 1) / cp);
+    for (long w = want; w >= 1; --w) {
+        cp = (P + w - 1) / w;
+        cp = ((cp + 31) / 32) * 32;
+        c = 0;
+        for (int l = 0; l < p->nseg; ++l) {
+            p->seg_chunk0[l] = c;
+            const long pl = (long)p->B * p->seg_H[l] * p->seg_W[l];
+            c += (int)((pl + cp - 1) / cp);
+        }
+        if (!fit || c <= want || c <= p->nseg) break;
     }
     p->seg_chunk0[p->nseg] = c;
     p->seg_chunk_pixels = (int)cp;

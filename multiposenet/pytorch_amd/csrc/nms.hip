@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(1024) score_filter_kernel(const float* __restr
 struct NmsBatch {
     const float* dets; long dets_stride;         // candidate rows [n][5] per image (floats between images)
     const int* counts; int n_host;
-    char* ws; long ws_stride;                    // per image: sorted [nmax*5 f32] | order [nmax i32] | remv [cb u64] | mask [nmax*cb u64]
+    char* ws; long ws_stride;                    // per image: sorted [nmax*5 f32] | order [nmax i32] | remv [cb u64] | mask (upper triangle, packed)
     long off_order, off_remv, off_mask;
     int cb;                                      // mask words per row = ceil(nmax / 64)
     int cap;                                     // 0, or: only the `cap` best-scored candidates of an image enter the suppression
@@ -103,6 +103,14 @@ __device__ __forceinline__ int nb_all(const NmsBatch& q, int b) { return q.count
 __device__ __forceinline__ int nb_count(const NmsBatch& q, int b) {
     const int n = nb_all(q, b);
     return (q.cap > 0 && n > q.cap) ? q.cap : n;
+}
+
+// The suppression mask is stored as its UPPER TRIANGLE only (the lower half is never written by nms_mask_kernel nor read by the scan —
+// nms_kernel.cu allocates it all the same, nms_cuda.c:28): row r (tile row rb = r / 64) keeps the words of column tiles rb .. cb - 1,
+// rows of a tile row back to back.  Word (r, j >= rb) sits at nms_tri_row(r, cb) + (j - rb); 64 * cb (cb + 1) / 2 words per image.
+__device__ __forceinline__ long nms_tri_row(int r, int cb) {
+    const long rb = r >> 6;
+    return 64 * (rb * cb - rb * (rb - 1) / 2) + (long)(r & 63) * (cb - rb);
 }
 
 __global__ void nms_rank_kernel(const NmsBatch q) {
@@ -176,7 +184,7 @@ __global__ void __launch_bounds__(64) nms_mask_kernel(const NmsBatch q, float th
         const bool hit = (mode == 0) ? (iou > thresh) : (iou >= thresh);
         if (hit && i >= start) bits |= 1ull << i;
     }
-    if (row < n) mask[(long)row * cb + col_blk] = bits;
+    if (row < n) mask[nms_tri_row(row, cb) + (col_blk - row_blk)] = bits;
 }
 
 // one workgroup of 1024 threads per image
@@ -199,7 +207,7 @@ __global__ void __launch_bounds__(1024) nms_scan_kernel(const NmsBatch q, int64_
     for (int bi = 0; bi < cbn; ++bi) {
         if (tid < 64) {
             const int row = bi * 64 + tid;
-            const unsigned long long diag = (row < n) ? mask[(long)row * cb + bi] : 0ull;
+            const unsigned long long diag = (row < n) ? mask[nms_tri_row(row, cb)] : 0ull;
             unsigned long long cur = remv[bi];
             unsigned long long kept = 0ull;
             const int lim = (n - bi * 64) < 64 ? (n - bi * 64) : 64;
@@ -222,7 +230,7 @@ __global__ void __launch_bounds__(1024) nms_scan_kernel(const NmsBatch q, int64_
                 while (k) {
                     const int t = __ffsll((long long)k) - 1;
                     k &= k - 1ull;
-                    acc |= mask[(long)(bi * 64 + t) * cb + j];
+                    acc |= mask[nms_tri_row(bi * 64 + t, cb) + (j - bi)];
                 }
                 remv[j] = acc;
             }
@@ -305,7 +313,7 @@ inline NmsLayout nms_layout(long nmax) {
     l.off_order = align_up(nmax * 5 * 4, 256);
     l.off_remv = l.off_order + align_up(nmax * 4, 256);
     l.off_mask = l.off_remv + align_up((long)l.cb * 8, 256);
-    l.total = l.off_mask + align_up(nmax * (long)l.cb * 8, 256);
+    l.total = l.off_mask + align_up(64L * ((long)l.cb * (l.cb + 1) / 2) * 8, 256);      // upper triangle only (nms_tri_row)
     return l;
 }
 inline int launch_nms(const float* dets, long dets_stride, const int* counts, int n_host, int B, long nmax, float thresh, int mode,

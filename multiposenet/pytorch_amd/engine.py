@@ -38,6 +38,7 @@ class Ctx(object):
         self.wt_ready = None     # event: the transposed weight copies (made on the side stream) are complete
         self.bnb = {}            # id(BN output Act) -> per-tile backward statistics produced by the launch that completed its gradient
         self.fwd_side_join = False   # forward work is in flight on the side stream (Engine.det_pyramid): join before it is consumed
+        self.cls_ev = None       # event: the class input gradients of conv2 (side stream) are complete (Engine.wait_class_grads)
         self.schedule = None     # bucket schedule of this backward pass: the data-parallel GradReducer, or its process-group-free
                                  # twin when one GPU runs per-bucket optimizer updates (Engine.run_backward)
         self.lazy_res = {}       # id(Act) -> (dz, mask bits): shortcut gradient dz * (z > 0) NOT materialised; the convolution whose
@@ -101,6 +102,9 @@ class Engine(object):
         # torch.cat((up8(q5), up4(q4), up2(q3), q2), 1) -> conv2 (posenet.py:311-315): the 512-channel tensor is never written; conv2's
         # forward and weight-gradient launches gather from the four members, its input gradient lands in q2's gradient directly
         self.virtual_concat = os.environ.get("MPN_VIRTUAL_CONCAT", "1") != "0"
+        # ... and its x8 / x4 members do not go through conv2 at full resolution at all: nine position-class maps each at their own
+        # resolution (csrc/conv2cls.hip), expanded into conv2's epilogue; conv2 itself contracts over the x2 / x1 members only
+        self.conv2_classes = os.environ.get("MPN_CONV2_CLASSES", "1") != "0"
 
     def side_stream(self, device):
         """Second HIP stream for weight/bias gradients.  They are off the backward critical path (only the
@@ -650,6 +654,122 @@ class Engine(object):
                     ctx.set_grad(s_, g)
                 off += s_.Cs
 
+    # ------------------------------------------------------------------ conv2 by position classes
+    def conv_cat_cls(self, ctx, srcs, H, W, layer, act=1):
+        """relu(layer(cat(up8(q5), up4(q4), up2(q3), q2))) with the x8 / x4 members as position-class maps (csrc/conv2cls.hip; ops.conv2cls_*).
+        Side stream: combined filters, the two class convolutions, the expansion; main stream: the 3x3 convolution over the virtual
+        concatenation of (q3, q2) with the expanded maps as its residual.  Backward mirrors it (_conv_cat_cls_bwd)."""
+        q5, q4, q3, q2 = srcs
+        O, I, R, S, stride, pad = _geom(layer)
+        C = I // 4
+        bias = layer.bias
+        dev = q2.t.device
+        ar = self.m._arena
+        need_x = ctx.train and any(s_.needs_grad for s_ in srcs)
+        st = {}
+
+        def classes():
+            st["ops"] = wo = ops.Conv2ClsOperands(ar.data_seg(layer.weight), O, C, self.cdt, need_x)
+            m8, _ = ops.conv_forward(q5, wo.wc[0], 9 * O, 3, 3, 1, 1, out_f32=True)
+            m4, _ = ops.conv_forward(q4, wo.wc[1], 9 * O, 3, 3, 1, 1, out_f32=True)
+            st["e"] = ops.conv2cls_expand(m8, m4, q2.B, H, W, O, self.cdt)
+            st["keep"] = (m8, m4)
+        side = self.side_stream(dev)
+        if side is not None:
+            self._on_side(ctx, dev, (q5, q4, st), classes)
+            self.flush_side(ctx, dev)
+            ev = torch.cuda.Event()
+            gpu_op(ev.record, side)
+            gpu_op(torch.cuda.current_stream(dev).wait_event, ev)       # (issued here; the q3 / q2 branches were enqueued before this call)
+        else:
+            classes()
+        wo = st["ops"]
+        y = ops.conv_forward_cat([q3, q2], H, W, wo.wm, O, bias=bias.data if bias is not None else None, act=3 if act == 1 else act, res=st["e"])
+        y.relu_out = act == 1
+        if ctx.train:
+            y.needs_grad = bool(need_x or layer.weight.requires_grad or (bias is not None and bias.requires_grad))
+            if y.needs_grad:
+                self._note_use(ctx, layer.weight)
+                self._note_use(ctx, bias)
+                ctx.tape.append(lambda: self._conv_cat_cls_bwd(ctx, srcs, H, W, layer, y, act, wo))
+        if side is not None:
+            ctx.side_keep.append((st, y))
+        return y
+
+    def _conv_cat_cls_bwd(self, ctx, srcs, H, W, layer, y, act, wo):
+        q5, q4, q3, q2 = srcs
+        dy = ctx.pop_grad(y)
+        O, I, R, S, stride, pad = _geom(layer)
+        C = I // 4
+        bias = layer.bias
+        wg = layer.weight.requires_grad
+        bg = bias is not None and bias.requires_grad
+        if dy is None:
+            if wg:
+                self._grad_done(ctx, layer.weight)
+            if bg:
+                self._grad_done(ctx, bias)
+            return
+        if act == 1:
+            dy = ops.relu_backward(dy, y)
+        ar = self.m._arena
+        dev = dy.t.device
+        need_x = any(s_.needs_grad for s_ in srcs)
+        g5 = g4 = None
+        if need_x:
+            g5 = Act(torch.empty_like(q5.t), q5.C)
+            g4 = Act(torch.empty_like(q4.t), q4.C)
+
+        def class_side():
+            # everything of the x8 / x4 members: class pooling of dy and the per-tap sums, their input gradients (1x1 over nine taps;
+            # consumed by the main stream a dozen launches later: ctx.cls_ev), the per-tap filter gradients, the main part's weight
+            # gradient and the fold into dW
+            p8, p4 = ops.conv2cls_pool(dy)
+            g8, g4t = ops.conv2cls_tapsum(p8), ops.conv2cls_tapsum(p4)
+            if need_x:
+                ops.conv_forward(g8, wo.wtap_t[0], C, 1, 1, 1, 0, mode=1, out_hw=(q5.H, q5.W), cin=9 * O, out=g5)
+                ops.conv_forward(g4t, wo.wtap_t[1], C, 1, 1, 1, 0, mode=1, out_hw=(q4.H, q4.W), cin=9 * O, out=g4)
+                ev = torch.cuda.Event()
+                gpu_op(ev.record, ops.stream_obj() if ops.stream_obj() is not None else torch.cuda.current_stream(dev))
+                ctx.cls_ev = ev
+            if wg or bg:
+                n = wo.nm + 2 * wo.nt
+                dcomb = torch.empty(n, dtype=torch.float32, device=dev)
+                call("mpn_fill_f32", ops.ptr(dcomb), 0.0, n, ops.stream_ptr())
+                done = False
+                if wg:
+                    done = ops.conv_wgrad_cat([q3, q2], H, W, dy, dcomb[: wo.nm], O, db=ar.grad_seg(bias) if bg else None)
+                    ops.conv_wgrad(q5, g8, dcomb[wo.nm: wo.nm + wo.nt], 9 * O, 1, 1, 1, 0)
+                    ops.conv_wgrad(q4, g4t, dcomb[wo.nm + wo.nt:], 9 * O, 1, 1, 1, 0)
+                    call("mpn_conv2cls_fold", ops.ptr(dcomb), ops.ptr(ar.grad_seg(layer.weight)), O, C, ops.stream_ptr())
+                if bg and not done:
+                    ops.bias_grad(dy, ar.grad_seg(bias), O)
+                ctx.side_keep.append((dcomb,))
+            ctx.side_keep.append((p8, p4, g8, g4t))
+        self._on_side(ctx, dev, (srcs, dy, g5, g4, wo), class_side)
+        if self.side_stream(dev) is not None:
+            self.flush_side(ctx, dev)
+        if wg:
+            self._grad_done(ctx, layer.weight)
+        if bg:
+            self._grad_done(ctx, bias)
+        if need_x:
+            ctx.set_grad(q5, g5)
+            ctx.set_grad(q4, g4)
+            d_all = Act(torch.empty((dy.B, H, W, 2 * C), dtype=dy.t.dtype, device=dev), 2 * C)
+            ops.conv_forward(dy, wo.wm_t, 2 * C, 3, 3, 1, 1, mode=1, out_hw=(H, W), cin=O, out=d_all)
+            for s_, off in ((q3, 0), (q2, C)):
+                g = Act(torch.empty_like(s_.t), s_.C)
+                ops.upsample_slice_backward(d_all, g, off)
+                ctx.set_grad(s_, g)
+
+    def wait_class_grads(self, ctx, device):
+        """Tape marker in front of the consumers of the class input gradients (keypoint_head): they were produced on the side stream."""
+        ev = getattr(ctx, "cls_ev", None)
+        if ev is not None:
+            gpu_op(torch.cuda.current_stream(device).wait_event, ev)
+            ctx.cls_ev = None
+
     def export(self, ctx, src, C, Ho, Wo, slot):
         """Internal padded tensor -> exact f32 API tensor (nearest up-sampled to Ho x Wo)."""
         out = ops.export_f32(src, C, Ho, Wo)
@@ -812,9 +932,15 @@ class Engine(object):
                 saved.append(self.export_internal(ctx, k, "k%d" % i) if internal else self.export(ctx, k, 19, Ho, Wo, "k%d" % i))
         q5, _ = self.conv(ctx, self.conv(ctx, p5, m.convt1)[0], m.convs1)
         q4, _ = self.conv(ctx, self.conv(ctx, p4, m.convt2)[0], m.convs2)
+        if ctx.train:
+            # backward: the gradients of q5 / q4 may come from the side stream (conv2 by position classes); this marker runs right
+            # before the first launch that reads them (the tape is walked backwards)
+            ctx.tape.append(lambda: self.wait_class_grads(ctx, p2.t.device))
         q3, _ = self.conv(ctx, self.conv(ctx, p3, m.convt3)[0], m.convs3)
         q2, _ = self.conv(ctx, self.conv(ctx, p2, m.convt4)[0], m.convs4)
-        if self.virtual_concat and ops.cat_supported([q5, q4, q3, q2], Ho, Wo):
+        if self.virtual_concat and self.conv2_classes and ops.conv2cls_supported([q5, q4, q3, q2], Ho, Wo):
+            h = self.conv_cat_cls(ctx, [q5, q4, q3, q2], Ho, Wo, m.conv2, act=1)
+        elif self.virtual_concat and ops.cat_supported([q5, q4, q3, q2], Ho, Wo):
             h = self.conv_cat(ctx, [q5, q4, q3, q2], Ho, Wo, m.conv2, act=1)
         else:
             cat = self.concat_up(ctx, [q5, q4, q3, q2], Ho, Wo)

@@ -320,9 +320,10 @@ def cat_supported(srcs, H, W):
     return True
 
 
-def conv_forward_cat(srcs, H, W, w, Cout, bias=None, act=0, tag=""):
+def conv_forward_cat(srcs, H, W, w, Cout, bias=None, act=0, tag="", res=None):
     """3x3 / stride 1 / pad 1 convolution over torch.cat([nearest_upsample(s) for s in srcs], 1) WITHOUT materialising it
-    (posenet.py:311-315: the 512-channel input of conv2).  w: [Cout][3][3][len(srcs) * 128]."""
+    (posenet.py:311-315: the 512-channel input of conv2).  w: [Cout][3][3][len(srcs) * 128].  res: same-size tensor added in the
+    epilogue (act 3 = ReLU after it): the expanded class maps of the members conv2cls_* serve."""
     x0 = srcs[0]
     dt, dev = x0.t.dtype, x0.t.device
     out = Act.empty(x0.B, H, W, Cout, dt, dev, False, tag)
@@ -336,6 +337,11 @@ def conv_forward_cat(srcs, H, W, w, Cout, bias=None, act=0, tag=""):
     p.y_sB, p.y_sP = H * W * out.Cs, out.Cs
     p.R, p.S, p.stride, p.pad = 3, 3, 1, 1
     p.act, p.dtype = act, dtype_code(dt)
+    if res is not None:
+        assert res.t.dtype == dt and (res.B, res.H, res.W, res.Cs) == (out.B, H, W, out.Cs)
+        p.res, p.res_mode = res.t.data_ptr(), 1
+        p.res_sB, p.res_sP = H * W * res.Cs, res.Cs
+        p.res_H, p.res_W = H, W
     if KERNEL_EVENTS.on:
         e0 = KERNEL_EVENTS.begin()
         call("mpn_conv_forward", ctypes.byref(p), stream_ptr())
@@ -389,6 +395,65 @@ def conv_wgrad_cat(srcs, H, W, dy, dw, Cout, db=None):
     else:
         call("mpn_conv_wgrad", ctypes.byref(p), stream_ptr())
     return fused_db
+
+
+# ---- conv2 of the keypoint head by position classes (csrc/conv2cls.hip) -------------------------------------------------------------
+def conv2cls_supported(srcs, H, W):
+    """The class formulation serves exactly posenet.py:311-315's geometry: four 128-channel 16-bit members at 1/8, 1/4, 1/2, 1/1 of an
+    H x W (multiples of 8) output."""
+    if not cat_supported(srcs, H, W) or len(srcs) != 4 or H % 8 or W % 8:
+        return False
+    return [(H // a.H, W // a.W) for a in srcs] == [(8, 8), (4, 4), (2, 2), (1, 1)]
+
+
+class Conv2ClsOperands(object):
+    """Per-forward operands of the class formulation, all derived from the f32 master filter [O][3][3][4 C] in four launches: the
+    combined filters (f32), their compute-dtype copies, and the transposed (input-gradient) copies when a backward pass will follow."""
+
+    def __init__(self, w_master, O, C, dtype, want_t):
+        dev = w_master.device
+        n = call("mpn_conv2cls_comb_elems", O, C)
+        self.O, self.C = O, C
+        self.nm, self.nc, self.nt = O * 9 * 2 * C, 9 * O * 9 * C, 9 * O * C
+        comb32 = torch.empty(n, dtype=torch.float32, device=dev)
+        call("mpn_conv2cls_combine", ptr(w_master), ptr(comb32), O, C, stream_ptr())
+        nf = self.nm + 2 * self.nc                                              # forward operands: main filter + the two frame-filter sets
+        self.comb = torch.empty(nf, dtype=dtype, device=dev)
+        cast_lowp(comb32[:nf], self.comb)
+        self.wm = self.comb[: self.nm]                                         # [O][3][3][2C]
+        self.wc = [self.comb[self.nm + m * self.nc: self.nm + (m + 1) * self.nc] for m in range(2)]      # [9 O][3][3][C], members q5 / q4
+        self.wm_t = self.wtap_t = None
+        if want_t:
+            self.wm_t = torch.empty((2 * C, 3, 3, O), dtype=dtype, device=dev)
+            weight_transpose(comb32[: self.nm], self.wm_t, O, 9, 2 * C, O)
+            self.wtap_t = []                                                    # [C][1][1][9 O]: the member as nine 1x1 convolutions, transposed
+            for m in range(2):
+                t = torch.empty((C, 1, 1, 9 * O), dtype=dtype, device=dev)
+                weight_transpose(comb32[nf + m * self.nt: nf + (m + 1) * self.nt], t, 9 * O, 1, C, 9 * O)
+                self.wtap_t.append(t)
+        self.keep = comb32
+
+
+def conv2cls_expand(m8, m4, B, H, W, O, dtype):
+    e = Act(torch.empty((B, H, W, O), dtype=dtype, device=m8.t.device), O)
+    call("mpn_conv2cls_expand", ptr(m8.t), ptr(m4.t), ptr(e.t), B, H, W, O, dtype_code(dtype), stream_ptr())
+    return e
+
+
+def conv2cls_pool(dy):
+    """(P8 [B, H/8, W/8, 9 O], P4 [B, H/4, W/4, 9 O]): per-class sums of dy over 8 x 8 / 4 x 4 blocks (one pass over dy)."""
+    B, H, W, O = dy.B, dy.H, dy.W, dy.Cs
+    p8 = Act(torch.empty((B, H // 8, W // 8, 9 * O), dtype=dy.t.dtype, device=dy.t.device), 9 * O)
+    p4 = Act(torch.empty((B, H // 4, W // 4, 9 * O), dtype=dy.t.dtype, device=dy.t.device), 9 * O)
+    call("mpn_conv2cls_pool", ptr(dy.t), ptr(p8.t), ptr(p4.t), B, H, W, O, dtype_code(dy.t.dtype), stream_ptr())
+    return p8, p4
+
+
+def conv2cls_tapsum(pc):
+    """Class sums [B, h, w, 9 O] -> per-tap sums of the same shape (csrc/conv2cls.hip: conv2cls_tapsum_kernel)."""
+    g = Act(torch.empty_like(pc.t), pc.C)
+    call("mpn_conv2cls_tapsum", ptr(pc.t), ptr(g.t), pc.B, pc.H, pc.W, pc.Cs // 9, dtype_code(pc.t.dtype), stream_ptr())
+    return g
 
 
 def conv_out_hw(H, W, R, S, stride, pad):
@@ -479,7 +544,7 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         tiles = call("mpn_conv_stats_tiles", ctypes.byref(p))
         stats = torch.empty((tiles, Cout, 2), dtype=torch.float32, device=dev)
         p.stats = stats.data_ptr()
-        if bn_fin is not None and fin_in_launch(tiles):
+        if bn_fin is not None and fin_in_launch(tiles, Cout):
             # the last workgroup of every channel tile turns the tile partials into the BatchNorm coefficients (no finalize launch):
             # the BNState comes back in the stats slot
             gamma, beta, rm, rv, momentum, eps = bn_fin
@@ -509,7 +574,7 @@ def conv_forward(x, w, Cout, R, S, stride, pad, bias=None, scale=None, act=0, re
         p.bnb_mean, p.bnb_invstd = st.mean.data_ptr(), st.invstd.data_ptr()
         p.bnb_scale, p.bnb_shift = st.scale.data_ptr(), st.shift.data_ptr()
         p.bnb_relu = 1 if relu else 0
-        if _cls is None and len(bnb) > 4 and bnb[4] is not None and fin_in_launch(tiles):
+        if _cls is None and len(bnb) > 4 and bnb[4] is not None and fin_in_launch(tiles, Cout):
             # ... and the last workgroup of every channel tile finishes the reduction: dgamma / dbeta and the (k1, k2, k3) of
             # dy = k1*g + k2*y + k3 (mpn_bn_bwd_finalize's work); the coefficient tensor comes back in the stats slot
             gamma, train, dgamma, dbeta = bnb[4]
@@ -673,8 +738,10 @@ FIN_MAX_TILES = int(os.environ.get("MPN_BN_FIN_MAX_TILES", "64"))
 FIN_COUNTERS = 64
 
 
-def fin_in_launch(tiles):
-    return tiles <= FIN_MAX_TILES
+def fin_in_launch(tiles, Cout=2):
+    """The in-launch finalize reads the partial table as float4 pairs of channels: even widths only (every BatchNorm of the network is;
+    an odd width takes the separate finalize launch instead of failing with BADARG — ADVICE r5)."""
+    return tiles <= FIN_MAX_TILES and Cout % 2 == 0
 
 
 def fin_attach(p, tiles, Cout, device):
@@ -931,12 +998,12 @@ def detect_batched(boxes, scores, score_thresh, iou_thresh, mode=0, ws_limit=4 <
         pre_nms_top_n = nms_pre_topn_env()
     top = int(pre_nms_top_n) if pre_nms_top_n else 0
     if top == 0 and nmax > 32768 and not _NMS_WARNED:
-        # the reference's behaviour (every candidate above the score threshold enters the suppression) costs an N x N / 64 mask per image:
-        # 134 MB at 32 768 candidates, 1.2 GB at 100 000 — say so once instead of silently taking seconds
+        # the reference's behaviour (every candidate above the score threshold enters the suppression) costs the upper triangle of an
+        # N x N / 64 mask per image: 67 MB at 32 768 candidates, 0.6 GB at 100 000 — say so once instead of silently taking seconds
         import warnings
         _NMS_WARNED.append(True)
-        warnings.warn("NMS over %d candidates in one image (N x N / 64 mask = %.0f MB per image); pass pre_nms_top_n or set MPN_NMS_PRE_TOPN "
-                      "to bound it (not in the reference)" % (nmax, nmax * float(nmax) / 64 * 8 / 1e6))
+        warnings.warn("NMS over %d candidates in one image (upper-triangle N x N / 128 mask = %.0f MB per image); pass pre_nms_top_n or set "
+                      "MPN_NMS_PRE_TOPN to bound it (not in the reference)" % (nmax, nmax * float(nmax) / 128 * 8 / 1e6))
     if top > 0:
         nmax = min(nmax, top)                          # rows of the sort / mask scratch and of the outputs
     keep = torch.empty((B, nmax), dtype=torch.int64, device=dev)

@@ -172,10 +172,49 @@ def keypoint_head(sd, kp_feats, with_intermediate):
     q4 = _conv(sd, "convs2", _conv(sd, "convt2", p4, padding=1), padding=1)
     q3 = _conv(sd, "convs3", _conv(sd, "convt3", p3, padding=1), padding=1)
     q2 = _conv(sd, "convs4", _conv(sd, "convt4", p2, padding=1), padding=1)
-    cat = torch.cat((_up(q5, 8), _up(q4, 4), _up(q3, 2), q2), 1)            # posenet.py:311-315
-    pred = _conv(sd, "convfin", F.relu(_conv(sd, "conv2", cat, padding=1)), f32_out=True)
+    if _QUANT is not None and CONV2_CLASSES and q2.shape[2] % 8 == 0 and q2.shape[3] % 8 == 0:
+        h = _conv2_position_classes(sd, q5, q4, q3, q2)                     # the ROUNDING MODEL of csrc/conv2cls.hip; same mathematics
+    else:
+        cat = torch.cat((_up(q5, 8), _up(q4, 4), _up(q3, 2), q2), 1)        # posenet.py:311-315
+        h = F.relu(_conv(sd, "conv2", cat, padding=1))
+    pred = _conv(sd, "convfin", h, f32_out=True)
     saved.append(pred)
     return pred, saved
+
+
+# Rounding model only (never used without `rounding(...)`): the product evaluates conv2 over cat(up8(q5), up4(q4), up2(q3), q2) with the
+# x8 / x4 members as nine position-class maps each (csrc/conv2cls.hip).  Mathematically identical to posenet.py:311-315 (checked to
+# 3e-7 in fp32 by tests/test_round6_cpu.py); what differs is WHERE 16-bit rounding happens, and an oracle "that rounds where the kernels
+# round" has to follow: the frame filters are rounded AFTER the taps were summed in f32, the expanded class maps are rounded once, the
+# main part (x2 / x1 members + bias) is rounded when its tile is staged, and the sum is rounded after the ReLU.
+CONV2_CLASSES = False
+_CLS_ROWS = {0: ((0,), (1, 2), ()), 1: ((), (0, 1, 2), ()), 2: ((), (0, 1), (2,))}      # class -> original taps collected by frame tap u
+
+
+def _conv2_position_classes(sd, q5, q4, q3, q2):
+    w, b = sd["conv2.weight"], sd["conv2.bias"]
+    H, W = q2.shape[2], q2.shape[3]
+
+    def rq(t):          # operand copy in the 16-bit type, gradient straight through (as _conv does for weights)
+        return t if _QUANT is None else t + (t.detach().to(_QUANT).float() - t.detach())
+    e = 0
+    for q, s, c0 in ((q5, 8, 0), (q4, 4, 128)):
+        wm = w[:, c0: c0 + 128]
+        full = torch.zeros(q.shape[0], w.shape[0], H, W, dtype=q.dtype)
+        for a in range(s):
+            ca = 0 if a == 0 else (2 if a == s - 1 else 1)
+            for c in range(s):
+                cc = 0 if c == 0 else (2 if c == s - 1 else 1)
+                parts = []
+                for u in range(3):
+                    for v in range(3):
+                        taps = [wm[:, :, r, t_] for r in _CLS_ROWS[ca][u] for t_ in _CLS_ROWS[cc][v]]
+                        parts.append(sum(taps) if taps else torch.zeros_like(wm[:, :, 0, 0]))
+                fr = torch.stack(parts, -1).reshape(wm.shape[0], wm.shape[1], 3, 3)
+                full[:, :, a::s, c::s] = F.conv2d(q, rq(fr), None, padding=1)        # class map (f32), scattered to its pixels
+        e = e + full
+    main = F.conv2d(torch.cat((_up(q3, 2), q2), 1), rq(w[:, 256:]), b, padding=1)
+    return _q(F.relu(_q(main) + _q(e)))
 
 
 def _tower(sd, pre, x):

@@ -36,7 +36,16 @@ def _product(d_np, thr):
     off_mask = off_order + _align(n * 4) + _align(cb * 8)
     srt = raw[: n * 20].view(np.float32).reshape(n, 5).copy()
     order = raw[off_order: off_order + n * 4].view(np.int32).copy()
-    mask = raw[off_mask: off_mask + n * cb * 8].view(np.uint64).reshape(n, cb).copy()
+    # round 6: the workspace holds the UPPER TRIANGLE only (nms.hip: nms_tri_row) — row r keeps the words of column tiles r // 64 .. cb - 1;
+    # unpack into the dense [n, cb] form the reference kernel writes (lower half zero: the product never computes it)
+    tri = raw[off_mask: off_mask + 64 * (cb * (cb + 1) // 2) * 8].view(np.uint64)
+    assert nbytes == off_mask + _align(64 * (cb * (cb + 1) // 2) * 8), "workspace query does not match the packed layout"
+    mask = np.zeros((n, cb), dtype=np.uint64)
+    for rb in range(cb):
+        r0, r1 = rb * 64, min(n, rb * 64 + 64)
+        base = 64 * (rb * cb - rb * (rb - 1) // 2)
+        w = cb - rb
+        mask[r0:r1, rb:] = tri[base: base + (r1 - r0) * w].reshape(r1 - r0, w)
     return keep.cpu().numpy(), srt, order, mask
 
 

@@ -400,6 +400,8 @@ def test_virtual_concat_equals_the_materialised_concatenation(dtype):
     heat, wgt = (t(a).cuda() for a in weightgen.gen_keypoint_gt(811, Bn, S // 4, S // 4))
     bn_state = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
     outs = []
+    classes = m._engine.conv2_classes
+    m._engine.conv2_classes = False          # (round 6: the position-class form of conv2 has its own tests, tests/test_round6_gpu.py)
     for virt in (False, True):
         m._engine.virtual_concat = virt
         m.load_state_dict(bn_state, strict=False)
@@ -410,7 +412,7 @@ def test_virtual_concat_equals_the_materialised_concatenation(dtype):
         loss.backward()
         torch.cuda.synchronize()
         outs.append((pred.detach().clone(), loss.detach().clone(), m._arena.grad_flat.clone()))
-    m._engine.virtual_concat = True
+    m._engine.virtual_concat, m._engine.conv2_classes = True, classes
     assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), "virtual concatenation changed the training step"
     report("virtual concatenation (conv2 of the keypoint head): forward / weight gradient / input gradient bit-identical to the "
            "materialised 512-channel tensor; whole keypoint step bit-identical")

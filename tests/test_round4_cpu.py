@@ -107,19 +107,23 @@ def _hot_kernels():
     for dt in DTYPES:
         for gen in (False, True):
             hot.append((mangled("conv_igemm_kernel", dt, 128, 128, False, gen, False, False), 3, 49152))     # 3 workgroups / CU (LDS: 3 x 48 KB)
-            hot.append((mangled("conv_igemm_kernel", dt, 256, 128, False, gen, False, False), 2, 73728))     # 2 workgroups / CU
+            if dt != "f":                                             # pick_tc() never takes the 256-row tile for f32: not instantiated
+                hot.append((mangled("conv_igemm_kernel", dt, 256, 128, False, gen, False, False), 2, 73728))     # 2 workgroups / CU
             hot.append((mangled("conv_igemm_kernel", dt, 64, 128, False, gen, False, False), 3, 36864))
         # the parity-class launches of the stride-2 input gradients (seven per step) take conv_igemm_kernel's extended instantiation
         hot.append((mangled("conv_igemm_kernel", dt, 128, 128, False, True, True, False), 3, 49152))
-        hot.append((mangled("conv_igemm_kernel", dt, 256, 128, False, True, True, False), 2, 73728))
         if dt == "f":
-            continue                                                  # the shared-tile 3x3 kernel, f32 outputs and the LDS-DMA weight gradient are 16-bit paths
+            continue                                                  # the shared-tile 3x3 kernel and the f32-output heads are 16-bit paths (f32 has its own
+                                                                      # LDS-DMA weight-gradient twins, below)
+        hot.append((mangled("conv_igemm_kernel", dt, 256, 128, False, True, True, False), 2, 73728))
         for gen in (False, True):
             hot.append((mangled("conv_igemm_s3_kernel", dt, 128, 128, False, gen, False, False), 3, 49152))
             hot.append((mangled("conv_igemm_s3_kernel", dt, 256, 128, False, gen, False, False), 2, 73728))
             hot.append((mangled("conv_igemm_s3_kernel", dt, 64, 128, False, gen, False, False), 3, 36864))
         # conv2 through the virtual concatenation (extended epilogue; the largest launch of cfg3 and cfg5)
         hot.append((mangled("conv_igemm_s3_kernel", dt, 256, 128, False, True, True, False), 2, 73728))
+        # round 6: the class convolutions of conv2 (csrc/conv2cls.hip): 128 -> 9 x 256 channels at 1/8 and 1/4 resolution, f32 class maps
+        hot.append((mangled("conv_igemm_s3_kernel", dt, 256, 128, True, False, False, False), 2, 73728))
         # f32 heads of the 16-bit network (convfin*, the detection outputs)
         hot.append((mangled("conv_igemm_kernel", dt, 128, 128, True, True, False, False), 3, 49152))
         hot.append((mangled("conv_igemm_s3_kernel", dt, 128, 128, True, True, False, False), 3, 49152))

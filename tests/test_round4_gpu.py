@@ -304,21 +304,35 @@ def test_bf16_pyramids_heads_and_stem_against_the_rounding_oracle():
         run_tape(ctx)
         compare("(i') detection pyramid", [_nchw(o) for o in outs_h], outs_o, xs_h, xs_o, ctx,
                 ("fpn.conv6.", "fpn.conv7.", "fpn.latlayer", "fpn.toplayer0.", "fpn.toplayer1.", "fpn.toplayer2."))
-        # ---- (ii) keypoint head: intermediate 1x1 heads (f32 out), convt / convs, conv2 over the virtual concatenation, convfin
-        ctx = fresh()
-        fs = [_bf16_randn(740 + i, B, 256, h, h) for i, h in enumerate((32, 16, 8, 4))]
-        xs_o = [f.clone().requires_grad_(True) for f in fs]
-        with po.rounding(Q):
-            pred_o, saved_o = po.keypoint_head(sd, [po._q(x) for x in xs_o], True)
-        outs_o = saved_o                                                    # [k2, k3, k4, k5 (up-sampled), pred], all f32 API tensors
-        gs = [torch.randn(o.shape, generator=torch.Generator().manual_seed(750 + i)) * 0.05 for i, o in enumerate(outs_o)]
-        torch.autograd.backward(outs_o, gs)
-        xs_h = [_act(f) for f in fs]
-        pred_h, saved_h = eng.keypoint_head(ctx, xs_h, True)
-        ctx.out_grads = {"k0": gs[0].cuda(), "k1": gs[1].cuda(), "k2": gs[2].cuda(), "k3": gs[3].cuda(), "pred": gs[4].cuda()}
-        run_tape(ctx)
-        compare("(ii) keypoint head (virtual concat)", [x.float().cpu() for x in saved_h + [pred_h]], outs_o, xs_h, xs_o, ctx,
-                ("convfin", "convt", "convs", "conv2."))
+        # ---- (ii) keypoint head: intermediate 1x1 heads (f32 out), convt / convs, conv2 over the virtual concatenation, convfin.
+        # Round 6: twice — conv2 through the plain virtual concatenation against the plain rounding model, and conv2 by position
+        # classes (csrc/conv2cls.hip, the default) against the rounding model of THAT formulation (oracle: _conv2_position_classes:
+        # frame filters rounded after the f32 tap sums, expanded class maps / staged main part / sum rounded once each).  The two
+        # formulations differ from each other by 3.4e-3 at the head outputs (the filters alone — bf16(w1 + w2) against bf16(w1) +
+        # bf16(w2) — account for 2.5e-3 at conv2's output, with equal distance to the fp32 truth); each must sit within the same
+        # 2e-3 of its own model: a wrong class map, a missing tap or a mis-pooled gradient shows up as 1e-1.
+        saved_cls = eng.conv2_classes
+        for use_classes in (False, True):
+            eng.conv2_classes = use_classes
+            po.CONV2_CLASSES = use_classes
+            ctx = fresh()
+            fs = [_bf16_randn(740 + i, B, 256, h, h) for i, h in enumerate((32, 16, 8, 4))]
+            xs_o = [f.clone().requires_grad_(True) for f in fs]
+            try:
+                with po.rounding(Q):
+                    pred_o, saved_o = po.keypoint_head(sd, [po._q(x) for x in xs_o], True)
+            finally:
+                po.CONV2_CLASSES = False
+            outs_o = saved_o                                                    # [k2, k3, k4, k5 (up-sampled), pred], all f32 API tensors
+            gs = [torch.randn(o.shape, generator=torch.Generator().manual_seed(750 + i)) * 0.05 for i, o in enumerate(outs_o)]
+            torch.autograd.backward(outs_o, gs)
+            xs_h = [_act(f) for f in fs]
+            pred_h, saved_h = eng.keypoint_head(ctx, xs_h, True)
+            ctx.out_grads = {"k0": gs[0].cuda(), "k1": gs[1].cuda(), "k2": gs[2].cuda(), "k3": gs[3].cuda(), "pred": gs[4].cuda()}
+            run_tape(ctx)
+            compare("(ii) keypoint head (%s)" % ("conv2 by position classes" if use_classes else "virtual concat"),
+                    [x.float().cpu() for x in saved_h + [pred_h]], outs_o, xs_h, xs_o, ctx, ("convfin", "convt", "convs", "conv2."))
+        eng.conv2_classes = saved_cls
         # ---- (iii) RetinaNet towers over the five-level pyramid (pyramid launches) + sigmoid edge
         ctx = fresh()
         ps = [_bf16_randn(760 + i, B, 256, h, h) for i, h in enumerate((16, 8, 4, 2, 1))]

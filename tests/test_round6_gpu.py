@@ -168,3 +168,72 @@ def test_rank_that_cannot_rendezvous_exits_3_with_a_diagnosis():
     assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert dt < 200, dt
     report("lone rank of a 2-rank job: exit 3 after %.0f s with: %s" % (dt, [ln for ln in res.stderr.splitlines() if "could not join" in ln][0][:160]))
+
+
+# ------------------------------------------------------------------------------------------------ conv2 by position classes
+def _head_run(m, feats, gs_pred, classes, overlap):
+    """keypoint_head forward + backward on fixed pyramid inputs / output gradient; returns (pred, input grads, conv2 dW, conv2 db, every head dparam)."""
+    from multiposenet.pytorch_amd import ops
+    from multiposenet.pytorch_amd.engine import Ctx
+    eng = m._engine
+    eng.conv2_classes, eng.overlap_wgrad = classes, overlap
+    m._arena.ensure_grads()
+    m._arena.grad_flat.zero_()
+    ctx = Ctx(True)
+    dt = m.compute_dtype
+    xs = [ops.Act(f.permute(0, 2, 3, 1).contiguous().to(dt).cuda(), f.shape[1], needs_grad=True) for f in feats]
+    pred, _ = eng.keypoint_head(ctx, xs, False, internal=True)
+    g = ops.Act(torch.zeros(pred.t.shape, dtype=dt, device=pred.t.device), pred.C)          # the loss kernel hands gradients over in the compute dtype
+    g.t[..., : pred.C] = gs_pred.permute(0, 2, 3, 1).to(dt).cuda()
+    ctx.out_grads = {"pred": g}
+    eng.run_backward(ctx, ctx.out_grads)
+    torch.cuda.synchronize()
+    out = pred.t[..., : pred.C].float().cpu()
+    return out, m.conv2.weight.grad.detach().float().cpu().clone(), m.conv2.bias.grad.detach().float().cpu().clone(), \
+        {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters() if n.startswith(("convt", "convs", "convfin.")) and p.grad is not None}
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv2_by_position_classes_equals_the_virtual_concatenation(dtype):
+    """conv2 of the keypoint head (posenet.py:311-315) with its x8 / x4 members as nine position-class maps each (csrc/conv2cls.hip:
+    combined filters, low-resolution class convolutions, expansion into conv2's epilogue; backward: class pooling of dy, low-resolution
+    input / filter gradients, fold) against (a) the same head through the plain virtual concatenation in the same 16-bit type and (b)
+    the fp32 kernels (materialised concatenation) as the truth: prediction, conv2's filter and bias gradients and every gradient that
+    flows on through q5 .. q2 (the convt / convs parameters).  The class path rounds one partial sum more (the expanded maps): its
+    error against fp32 may exceed the plain path's by at most 1.6x; serial and two-stream schedules give identical bits."""
+    from test_model_gpu import get_model
+    from test_round4_gpu import _rel, _bf16_randn
+    B, S = 2, 64                                               # pyramid levels 64, 32, 16, 8 -> conv2 at 64 x 64
+    feats = [_bf16_randn(900 + i, B, 256, S >> i, S >> i, relu=True) for i in range(4)]
+    g_pred = _bf16_randn(910, B, 18, S, S, scale=0.05)
+    ref_m = get_model(50, torch.float32)
+    ref_m.train()
+    saved = (ref_m._engine.conv2_classes, ref_m._engine.overlap_wgrad)
+    ref_m._prepare(torch.zeros((B, 3, 4 * S, 4 * S), device="cuda"))
+    ref = _head_run(ref_m, feats, g_pred, False, False)
+    ref_m._engine.conv2_classes, ref_m._engine.overlap_wgrad = saved
+    m = get_model(50, dtype)
+    m.train()
+    saved = (m._engine.conv2_classes, m._engine.overlap_wgrad)
+    m._prepare(torch.zeros((B, 3, 4 * S, 4 * S), device="cuda"))
+    try:
+        plain = _head_run(m, feats, g_pred, False, False)
+        cls = _head_run(m, feats, g_pred, True, False)
+        cls2 = _head_run(m, feats, g_pred, True, True)
+    finally:
+        m._engine.conv2_classes, m._engine.overlap_wgrad = saved
+    assert torch.equal(cls[0], cls2[0]) and torch.equal(cls[1], cls2[1]) and torch.equal(cls[2], cls2[2]), "schedules differ"
+    assert all(torch.equal(cls[3][k], cls2[3][k]) for k in cls[3])
+    rows = []
+    for name, i in (("prediction", 0), ("conv2 dW", 1), ("conv2 db", 2)):
+        ep, ec, d = _rel(plain[i], ref[i]), _rel(cls[i], ref[i]), _rel(cls[i], plain[i])
+        rows.append((name, ep, ec, d))
+    worst = max(((k, _rel(plain[3][k], ref[3][k]), _rel(cls[3][k], ref[3][k]), _rel(cls[3][k], plain[3][k])) for k in cls[3]), key=lambda r: r[2])
+    rows.append(("worst convt/convs/convfin dparam (%s)" % worst[0],) + worst[1:])
+    for name, ep, ec, d in rows:
+        report("conv2 by position classes (%s) %-52s vs fp32: plain %.2e, classes %.2e; classes vs plain %.2e" % (str(dtype)[6:], name, ep, ec, d))
+        assert ec <= 1.6 * ep + 2e-4, (name, ep, ec)
+        assert d <= 1.5 * ep + 1e-3, (name, d)                 # two 16-bit evaluations of the same quantity: no further apart than either is from fp32
+    # the four members really take different routes: the class filters' gradient slices are non-zero and differ from each other
+    dw = cls[1].reshape(256, 3, 3, 512)
+    assert all(float(dw[..., k * 128:(k + 1) * 128].abs().max()) > 0 for k in range(4))
