@@ -413,13 +413,16 @@ int mpn_step_log(const float* kp8, const float* det2, float* logv, void* stream)
  *   comb (f32, mpn_conv2cls_comb_elems(O, C) elements) = Wm [O][3][3][2C] | Wc8 [9 O][3][3][C] | Wc4 [9 O][3][3][C] (frame filters of
  *          the forward class convolutions) | Wtap8 [9 O][C] | Wtap4 [9 O][C] (row t * O + o = tap t of output channel o)
  *   combine: comb <- w;      fold: dw += dcomb, dcomb = dWm [O][3][3][2C] | dWtap8 [9 O][C] | dWtap4 [9 O][C]
- *   tapsum : g[b,i,j,t*O+:] (16-bit, like pc) = sum of dy over the output pixels whose tap t reads (i, j), from the class sums pc
- *   expand : e[b,y,x,:] (16-bit [B,H,W,O]) = m8[b, y/8, x/8, class * O + :] + m4[b, y/4, x/4, class * O + :]   (m: f32 [B,h,w,9 O])
- *   pool   : p8 / p4 (16-bit [B,H/s,W/s,9 O]) = per-class sums of dy (16-bit [B,H,W,O]) over s x s blocks; H, W multiples of 8
+ *   tapsum : g[b,i,j,t*O+:] (like pc) = sum of dy over the output pixels whose tap t reads (i, j), from the class sums pc
+ *   expand : e[b,y,x,:] ([B,H,W,O] in `dtype`) = m8[b, y/8, x/8, class * O + :] + m4[b, y/4, x/4, class * O + :]   (m: f32 [B,h,w,9 O])
+ *   classsum: m (f32 class maps) from t (f32 [B,h,w,9 O], t[..., tap * O + :] = the 1x1 convolution with filter tap `tap`): the forward
+ *            per tap, used where the zero taps of the frame filters cost matrix time (f32)
+ *   pool   : p8 / p4 ([B,H/s,W/s,9 O] in `dtype`) = per-class sums of dy ([B,H,W,O]) over s x s blocks; H, W multiples of 8
  * -------------------------------------------------------------------------------------------*/
 int64_t mpn_conv2cls_comb_elems(int O, int C);
 int mpn_conv2cls_combine(const float* w, float* comb, int O, int C, void* stream);
 int mpn_conv2cls_expand(const float* m8, const float* m4, void* e, int B, int H, int W, int O, int dtype, void* stream);
+int mpn_conv2cls_classsum(const float* t, float* m, int B, int h, int w, int O, void* stream);
 int mpn_conv2cls_pool(const void* dy, void* p8, void* p4, int B, int H, int W, int O, int dtype, void* stream);
 int mpn_conv2cls_tapsum(const void* pc, void* g, int B, int h, int w, int O, int dtype, void* stream);
 int mpn_conv2cls_fold(const float* dcomb, float* dw, int O, int C, void* stream);

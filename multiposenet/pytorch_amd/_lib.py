@@ -157,6 +157,7 @@ SIGNATURES = {
     "mpn_conv2cls_comb_elems": (_i64, [_i, _i]),
     "mpn_conv2cls_combine": (_i, [_vp, _vp, _i, _i, _vp]),
     "mpn_conv2cls_expand": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mpn_conv2cls_classsum": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "mpn_conv2cls_pool": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mpn_conv2cls_tapsum": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mpn_conv2cls_fold": (_i, [_vp, _vp, _i, _i, _vp]),

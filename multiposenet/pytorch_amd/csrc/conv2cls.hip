@@ -34,6 +34,8 @@ __device__ __forceinline__ unsigned cls_taps(int ca, int u) {
     const unsigned tbl = (0x1u) | (0x6u << 3) | (0x0u << 6) | (0x0u << 9) | (0x7u << 12) | (0x0u << 15) | (0x0u << 18) | (0x3u << 21) | (0x4u << 24);
     return (tbl >> ((ca * 3 + u) * 3)) & 7u;
 }
+// the frame tap of class ca that original tap r lands on
+__device__ __forceinline__ int cls_frame(int ca, int r) { return ca == 0 ? (r == 0 ? 0 : 1) : (ca == 1 ? 1 : (r == 2 ? 2 : 1)); }
 // class of offset a inside an s-pixel block
 __device__ __forceinline__ int cls_of(int a, int s) { return a == 0 ? 0 : (a == s - 1 ? 2 : 1); }
 
@@ -82,10 +84,39 @@ __global__ void conv2cls_combine_kernel(const float* __restrict__ w, float* __re
     comb[i] = acc;
 }
 
-// E[b, y, x, o] = M8[b, y / 8, x / 8, cls * O + o] + M4[b, y / 4, x / 4, cls' * O + o]; 8 channels per thread, f32 sums, one rounding
+// four elements as floats: 8 bytes of a 16-bit type, 16 bytes of float
+template <typename T> struct Vec8 {
+    float v[4];
+    __device__ __forceinline__ void load(const T* p) {
+        if constexpr (sizeof(T) == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(p);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+            const uint2 t = *reinterpret_cast<const uint2*>(p);
+            T e[4];
+            __builtin_memcpy(e, &t, 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = Elem<T>::ld(&e[k]);
+        }
+    }
+    __device__ __forceinline__ void store(T* p) const {
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            T e[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Elem<T>::st(&e[k], v[k]);
+            uint2 t;
+            __builtin_memcpy(&t, e, 8);
+            *reinterpret_cast<uint2*>(p) = t;
+        }
+    }
+};
+
+// E[b, y, x, o] = M8[b, y / 8, x / 8, cls * O + o] + M4[b, y / 4, x / 4, cls' * O + o]; 4 channels per thread, f32 sums, one rounding
 template <typename T>
 __global__ void __launch_bounds__(256) conv2cls_expand_kernel(const float* __restrict__ m8, const float* __restrict__ m4, T* __restrict__ e, int B, int H, int W, int O) {
-    const int og = O / 8;
+    const int og = O / 4;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * H * W * og) return;
     const int g = (int)(i % og);
@@ -94,35 +125,43 @@ __global__ void __launch_bounds__(256) conv2cls_expand_kernel(const float* __res
     const int y = (int)(p % H);
     const int b = (int)(p / H);
     const int k8 = cls_of(y & 7, 8) * 3 + cls_of(x & 7, 8), k4 = cls_of(y & 3, 4) * 3 + cls_of(x & 3, 4);
-    const float* __restrict__ a = m8 + (((long)b * (H >> 3) + (y >> 3)) * (W >> 3) + (x >> 3)) * 9 * O + (long)k8 * O + g * 8;
-    const float* __restrict__ c = m4 + (((long)b * (H >> 2) + (y >> 2)) * (W >> 2) + (x >> 2)) * 9 * O + (long)k4 * O + g * 8;
-    const float4 a0 = *reinterpret_cast<const float4*>(a), a1 = *reinterpret_cast<const float4*>(a + 4);
-    const float4 c0 = *reinterpret_cast<const float4*>(c), c1 = *reinterpret_cast<const float4*>(c + 4);
-    Vec16<T> v;
-    v.v[0] = a0.x + c0.x; v.v[1] = a0.y + c0.y; v.v[2] = a0.z + c0.z; v.v[3] = a0.w + c0.w;
-    v.v[4] = a1.x + c1.x; v.v[5] = a1.y + c1.y; v.v[6] = a1.z + c1.z; v.v[7] = a1.w + c1.w;
-    v.store(e + i * 8);
+    const float4 a = *reinterpret_cast<const float4*>(m8 + (((long)b * (H >> 3) + (y >> 3)) * (W >> 3) + (x >> 3)) * 9 * O + (long)k8 * O + g * 4);
+    const float4 c = *reinterpret_cast<const float4*>(m4 + (((long)b * (H >> 2) + (y >> 2)) * (W >> 2) + (x >> 2)) * 9 * O + (long)k4 * O + g * 4);
+    Vec8<T> v;
+    v.v[0] = a.x + c.x; v.v[1] = a.y + c.y; v.v[2] = a.z + c.z; v.v[3] = a.w + c.w;
+    v.store(e + i * 4);
 }
 
-// four 16-bit elements (8 bytes) as floats
-template <typename T> struct Vec8 {
-    float v[4];
-    __device__ __forceinline__ void load(const T* p) {
-        const uint2 t = *reinterpret_cast<const uint2*>(p);
-        T e[4];
-        __builtin_memcpy(e, &t, 8);
+// The forward per TAP (the f32 path, where the zero taps of the frame filters would cost real matrix time): T[b, i, j, t * O + o] is the
+// 1x1 convolution of the low-resolution tensor with filter tap t; class map k = (ca, cc) collects, for every original tap (r, s), the
+// product at the source pixel that tap reads — frame tap (u, v) = (cls_frame(ca, r), cls_frame(cc, s)) -> pixel (i + u - 1, j + v - 1),
+// zero outside.  Nine terms in (r, s) order; f32 in, f32 out, 4 channels per thread.
+__global__ void __launch_bounds__(256) conv2cls_classsum_kernel(const float* __restrict__ t, float* __restrict__ m, int B, int h, int w, int O) {
+    const int og = O / 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * h * w * 9 * og) return;
+    const int g = (int)(idx % og);
+    long q = idx / og;
+    const int k = (int)(q % 9); q /= 9;
+    const int j = (int)(q % w); q /= w;
+    const int i = (int)(q % h);
+    const int b = (int)(q / h);
+    const int ca = k / 3, cc = k - ca * 3;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = Elem<T>::ld(&e[k]);
-    }
-    __device__ __forceinline__ void store(T* p) const {
-        T e[4];
+    for (int r = 0; r < 3; ++r) {
+        const int ii = i + cls_frame(ca, r) - 1;
+        if (ii < 0 || ii >= h) continue;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) Elem<T>::st(&e[k], v[k]);
-        uint2 t;
-        __builtin_memcpy(&t, e, 8);
-        *reinterpret_cast<uint2*>(p) = t;
+        for (int s = 0; s < 3; ++s) {
+            const int jj = j + cls_frame(cc, s) - 1;
+            if (jj < 0 || jj >= w) continue;
+            const float4 v = *reinterpret_cast<const float4*>(t + (((long)b * h + ii) * w + jj) * 9 * O + (long)(r * 3 + s) * O + g * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
     }
-};
+    *reinterpret_cast<float4*>(m + (((long)b * h + i) * w + j) * 9 * O + (long)k * O + g * 4) = acc;
+}
 
 // Class pooling of dy [B, H, W, O]: P4[b, i, j, k * O + o] = sum over the pixels (4 i + a, 4 j + c) of class k of dy; P8 likewise over 8 x 8
 // blocks.  One thread per (4 x 4 quadrant, 4 channels): its 16 pixels (all sixteen 8-byte loads in flight) give the nine P4 sums
@@ -233,7 +272,7 @@ __global__ void conv2cls_fold_kernel(const float* __restrict__ dcomb, float* __r
 // f32 sums in this fixed order, one rounding.  8 channels per thread.
 template <typename T>
 __global__ void __launch_bounds__(256) conv2cls_tapsum_kernel(const T* __restrict__ pc, T* __restrict__ g, int B, int h, int w, int O) {
-    const int og = O / 8;
+    const int og = O / 4;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)B * h * w * 9 * og) return;
     const int gch = (int)(idx % og);
@@ -251,9 +290,7 @@ __global__ void __launch_bounds__(256) conv2cls_tapsum_kernel(const T* __restric
     if (s == 0) { dj[0] = 0; cj[0] = 1; dj[1] = 0; cj[1] = 2; dj[2] = 1; cj[2] = 0; }
     else if (s == 1) { dj[0] = 0; cj[0] = 0; dj[1] = 0; cj[1] = 1; dj[2] = 0; cj[2] = 2; }
     else { dj[0] = -1; cj[0] = 2; dj[1] = 0; cj[1] = 0; dj[2] = 0; cj[2] = 1; }
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const int ii = i + di[a];
@@ -262,16 +299,16 @@ __global__ void __launch_bounds__(256) conv2cls_tapsum_kernel(const T* __restric
         for (int c = 0; c < 3; ++c) {
             const int jj = j + dj[c];
             if (jj < 0 || jj >= w) continue;
-            Vec16<T> v;
-            v.load(pc + (((long)b * h + ii) * w + jj) * 9 * O + (long)(ci[a] * 3 + cj[c]) * O + gch * 8);
+            Vec8<T> v;
+            v.load(pc + (((long)b * h + ii) * w + jj) * 9 * O + (long)(ci[a] * 3 + cj[c]) * O + gch * 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += v.v[e];
+            for (int e = 0; e < 4; ++e) acc[e] += v.v[e];
         }
     }
-    Vec16<T> out;
+    Vec8<T> out;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) out.v[e] = acc[e];
-    out.store(g + (((long)b * h + i) * w + j) * 9 * O + (long)t * O + gch * 8);
+    for (int e = 0; e < 4; ++e) out.v[e] = acc[e];
+    out.store(g + (((long)b * h + i) * w + j) * 9 * O + (long)t * O + gch * 4);
 }
 
 inline unsigned nblk(long n, int t) { return (unsigned)((n + t - 1) / t); }
@@ -291,32 +328,34 @@ extern "C" int mpn_conv2cls_combine(const float* w, float* comb, int O, int C, v
 }
 
 extern "C" int mpn_conv2cls_expand(const float* m8, const float* m4, void* e, int B, int H, int W, int O, int dtype, void* stream) {
-    MPN_CHECK_ARG(m8 && m4 && e && B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && O > 0 && O % 8 == 0);
-    MPN_CHECK_ARG(dtype == MPN_BF16 || dtype == MPN_F16);
-    const long n = (long)B * H * W * (O / 8);
+    MPN_CHECK_ARG(m8 && m4 && e && B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && O > 0 && O % 8 == 0 && mpn_dtype_ok(dtype));
+    const long n = (long)B * H * W * (O / 4);
     MPN_CHECK_ARG(n < 0x7fffffffL * 256L);
-    if (dtype == MPN_BF16) hipLaunchKernelGGL((conv2cls_expand_kernel<bf16_t>), dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, m8, m4, (bf16_t*)e, B, H, W, O);
-    else hipLaunchKernelGGL((conv2cls_expand_kernel<f16_t>), dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, m8, m4, (f16_t*)e, B, H, W, O);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((conv2cls_expand_kernel<T>), dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, m8, m4, (T*)e, B, H, W, O));
+    return mpn_launch_status();
+}
+
+extern "C" int mpn_conv2cls_classsum(const float* t, float* m, int B, int h, int w, int O, void* stream) {
+    MPN_CHECK_ARG(t && m && B > 0 && h > 0 && w > 0 && O > 0 && O % 4 == 0);
+    const long n = (long)B * h * w * 9 * (O / 4);
+    MPN_CHECK_ARG(n < 0x7fffffffL * 256L);
+    hipLaunchKernelGGL(conv2cls_classsum_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, t, m, B, h, w, O);
     return mpn_launch_status();
 }
 
 extern "C" int mpn_conv2cls_pool(const void* dy, void* p8, void* p4, int B, int H, int W, int O, int dtype, void* stream) {
-    MPN_CHECK_ARG(dy && p8 && p4 && B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && O > 0 && O % 8 == 0);
-    MPN_CHECK_ARG(dtype == MPN_BF16 || dtype == MPN_F16);
+    MPN_CHECK_ARG(dy && p8 && p4 && B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && O > 0 && O % 8 == 0 && mpn_dtype_ok(dtype));
     const long n = (long)B * (H / 8) * (W / 8) * (O / 4) * 4;
     MPN_CHECK_ARG(n < 0x7fffffffL * 256L);
-    if (dtype == MPN_BF16) hipLaunchKernelGGL((conv2cls_pool_kernel<bf16_t>), dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)p8, (bf16_t*)p4, B, H, W, O);
-    else hipLaunchKernelGGL((conv2cls_pool_kernel<f16_t>), dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const f16_t*)dy, (f16_t*)p8, (f16_t*)p4, B, H, W, O);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((conv2cls_pool_kernel<T>), dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)p8, (T*)p4, B, H, W, O));
     return mpn_launch_status();
 }
 
 extern "C" int mpn_conv2cls_tapsum(const void* pc, void* g, int B, int h, int w, int O, int dtype, void* stream) {
-    MPN_CHECK_ARG(pc && g && B > 0 && h > 0 && w > 0 && O > 0 && O % 8 == 0);
-    MPN_CHECK_ARG(dtype == MPN_BF16 || dtype == MPN_F16);
-    const long n = (long)B * h * w * 9 * (O / 8);
+    MPN_CHECK_ARG(pc && g && B > 0 && h > 0 && w > 0 && O > 0 && O % 8 == 0 && mpn_dtype_ok(dtype));
+    const long n = (long)B * h * w * 9 * (O / 4);
     MPN_CHECK_ARG(n < 0x7fffffffL * 256L);
-    if (dtype == MPN_BF16) hipLaunchKernelGGL((conv2cls_tapsum_kernel<bf16_t>), dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pc, (bf16_t*)g, B, h, w, O);
-    else hipLaunchKernelGGL((conv2cls_tapsum_kernel<f16_t>), dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const f16_t*)pc, (f16_t*)g, B, h, w, O);
+    MPN_DISPATCH_T(dtype, hipLaunchKernelGGL((conv2cls_tapsum_kernel<T>), dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)pc, (T*)g, B, h, w, O));
     return mpn_launch_status();
 }
 

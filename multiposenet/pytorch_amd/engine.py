@@ -105,6 +105,10 @@ class Engine(object):
         # ... and its x8 / x4 members do not go through conv2 at full resolution at all: nine position-class maps each at their own
         # resolution (csrc/conv2cls.hip), expanded into conv2's epilogue; conv2 itself contracts over the x2 / x1 members only
         self.conv2_classes = os.environ.get("MPN_CONV2_CLASSES", "1") != "0"
+        self.conv2_classes_own_stream = os.environ.get("MPN_CONV2_CLS_STREAM", "0") != "0"      # measured: 35.73 -> 35.91 ms (profiles/r06_conv2_classes_ab.txt)
+        self._cls_stream = None
+        # forward class maps per TAP (1x1 convolutions + class sums) instead of the 3x3 frame filters: always in f32, optional in 16 bits
+        self.conv2_fwd_taps = os.environ.get("MPN_CONV2_FWD_TAPS", "0") != "0"
 
     def side_stream(self, device):
         """Second HIP stream for weight/bias gradients.  They are off the backward critical path (only the
@@ -116,6 +120,11 @@ class Engine(object):
         if self._side is None:
             self._side = torch.cuda.Stream(device=device)
         return self._side
+
+    def class_stream(self, device):
+        if self._cls_stream is None:
+            self._cls_stream = torch.cuda.Stream(device=device)
+        return self._cls_stream
 
     def _on_side(self, ctx, device, keep, fn, torch_ops=False):
         """Run fn() on the side stream, ordered after everything enqueued so far on the current stream.  Our own
@@ -655,48 +664,90 @@ class Engine(object):
                 off += s_.Cs
 
     # ------------------------------------------------------------------ conv2 by position classes
-    def conv_cat_cls(self, ctx, srcs, H, W, layer, act=1):
-        """relu(layer(cat(up8(q5), up4(q4), up2(q3), q2))) with the x8 / x4 members as position-class maps (csrc/conv2cls.hip; ops.conv2cls_*).
-        Side stream: combined filters, the two class convolutions, the expansion; main stream: the 3x3 convolution over the virtual
-        concatenation of (q3, q2) with the expanded maps as its residual.  Backward mirrors it (_conv_cat_cls_bwd)."""
-        q5, q4, q3, q2 = srcs
+    def conv2cls_begin(self, ctx, q5, q4, H, W, layer):
+        """First half of conv_cat_cls, issued as soon as the x8 / x4 members exist (before the x2 / x1 branches of the head are
+        enqueued, so that it runs under them): combined filters, the two class convolutions, the expansion — on the weight-gradient
+        side stream, or on a stream of its own (MPN_CONV2_CLS_STREAM=1) when that one is busy with the detection pyramid.  Returns
+        the state conv_cat_cls consumes, or None when the geometry is not the class formulation's."""
         O, I, R, S, stride, pad = _geom(layer)
+        if not (I == 512 and (R, S, stride, pad) == (3, 3, 1, 1) and H % 8 == 0 and W % 8 == 0 and q5.C == 128 and q4.C == 128
+                and q5.Cs == 128 and q4.Cs == 128 and (q5.H * 8, q5.W * 8, q4.H * 4, q4.W * 4) == (H, W, H, W) and q5.t.dtype == self.cdt):
+            return None
         C = I // 4
-        bias = layer.bias
-        dev = q2.t.device
+        dev = q5.t.device
         ar = self.m._arena
-        need_x = ctx.train and any(s_.needs_grad for s_ in srcs)
-        st = {}
+        st = {"need_x": bool(ctx.train and (q5.needs_grad or q4.needs_grad))}
 
         def classes():
-            st["ops"] = wo = ops.Conv2ClsOperands(ar.data_seg(layer.weight), O, C, self.cdt, need_x)
-            m8, _ = ops.conv_forward(q5, wo.wc[0], 9 * O, 3, 3, 1, 1, out_f32=True)
-            m4, _ = ops.conv_forward(q4, wo.wc[1], 9 * O, 3, 3, 1, 1, out_f32=True)
-            st["e"] = ops.conv2cls_expand(m8, m4, q2.B, H, W, O, self.cdt)
-            st["keep"] = (m8, m4)
+            # (the transposed operands are made whenever a tape is being recorded: whether q3 / q2 need gradients is not known yet)
+            st["ops"] = wo = ops.Conv2ClsOperands(ar.data_seg(layer.weight), O, C, self.cdt, ctx.train)
+            if self.conv2_fwd_taps or not ops.is16(self.cdt):
+                # per TAP: nine 1x1 convolutions + a low-resolution class sum — 9x fewer FLOPs than the frame filters, which matters where
+                # the matrix pipe is the limit (f32); in 16 bits the extra f32 pass over the maps costs what the frames waste
+                t8, _ = ops.conv_forward(q5, wo.wtap[0], 9 * O, 1, 1, 1, 0, out_f32=True)
+                t4, _ = ops.conv_forward(q4, wo.wtap[1], 9 * O, 1, 1, 1, 0, out_f32=True)
+                m8, m4 = ops.conv2cls_classsum(t8), ops.conv2cls_classsum(t4)
+                st["keep"] = (t8, t4, m8, m4)
+            else:
+                m8, _ = ops.conv_forward(q5, wo.wc[0], 9 * O, 3, 3, 1, 1, out_f32=True)
+                m4, _ = ops.conv_forward(q4, wo.wc[1], 9 * O, 3, 3, 1, 1, out_f32=True)
+                st["keep"] = (m8, m4)
+            st["e"] = ops.conv2cls_expand(m8, m4, q5.B, H, W, O, self.cdt)
         side = self.side_stream(dev)
-        if side is not None:
+        if side is not None and self.conv2_classes_own_stream:
+            side = self.class_stream(dev)
+            ev0 = torch.cuda.Event()
+            gpu_op(ev0.record, torch.cuda.current_stream(dev))
+            gpu_op(side.wait_event, ev0)
+            ops.push_stream(side)
+            try:
+                classes()
+            finally:
+                ops.pop_stream()
+        elif side is not None:
             self._on_side(ctx, dev, (q5, q4, st), classes)
             self.flush_side(ctx, dev)
-            ev = torch.cuda.Event()
-            gpu_op(ev.record, side)
-            gpu_op(torch.cuda.current_stream(dev).wait_event, ev)       # (issued here; the q3 / q2 branches were enqueued before this call)
         else:
             classes()
+        if side is not None:
+            st["ev"] = torch.cuda.Event()
+            gpu_op(st["ev"].record, side)
+            ctx.side_keep.append(st)
+        return st
+
+    def conv_cat_cls(self, ctx, srcs, H, W, layer, act, st):
+        """relu(layer(cat(up8(q5), up4(q4), up2(q3), q2))) with the x8 / x4 members as position-class maps (csrc/conv2cls.hip; ops.conv2cls_*):
+        the 3x3 convolution over the virtual concatenation of (q3, q2) with the expanded class maps of conv2cls_begin as its residual.
+        Backward mirrors it (_conv_cat_cls_bwd)."""
+        q5, q4, q3, q2 = srcs
+        O, I, R, S, stride, pad = _geom(layer)
+        bias = layer.bias
+        dev = q2.t.device
+        need_x = ctx.train and any(s_.needs_grad for s_ in srcs)
+        if "ev" in st:
+            gpu_op(torch.cuda.current_stream(dev).wait_event, st["ev"])
         wo = st["ops"]
-        y = ops.conv_forward_cat([q3, q2], H, W, wo.wm, O, bias=bias.data if bias is not None else None, act=3 if act == 1 else act, res=st["e"])
+        cat2 = None
+        if ops.is16(self.cdt):
+            y = ops.conv_forward_cat([q3, q2], H, W, wo.wm, O, bias=bias.data if bias is not None else None, act=3 if act == 1 else act, res=st["e"])
+        else:       # f32 has no virtual concatenation: the two remaining members are materialised (half of what concat_up writes)
+            C = I // 4
+            cat2 = Act(torch.empty((q2.B, H, W, 2 * C), dtype=q2.t.dtype, device=dev), 2 * C)
+            ops.upsample_slice(q3, cat2, 0)
+            ops.upsample_slice(q2, cat2, C)
+            y, _ = ops.conv_forward(cat2, wo.wm, O, 3, 3, 1, 1, bias=bias.data if bias is not None else None, act=3 if act == 1 else act,
+                                    res=st["e"], res_mode=1)
         y.relu_out = act == 1
         if ctx.train:
             y.needs_grad = bool(need_x or layer.weight.requires_grad or (bias is not None and bias.requires_grad))
             if y.needs_grad:
                 self._note_use(ctx, layer.weight)
                 self._note_use(ctx, bias)
-                ctx.tape.append(lambda: self._conv_cat_cls_bwd(ctx, srcs, H, W, layer, y, act, wo))
-        if side is not None:
-            ctx.side_keep.append((st, y))
+                ctx.tape.append(lambda: self._conv_cat_cls_bwd(ctx, srcs, H, W, layer, y, act, wo, cat2))
+        ctx.side_keep.append((st, y))
         return y
 
-    def _conv_cat_cls_bwd(self, ctx, srcs, H, W, layer, y, act, wo):
+    def _conv_cat_cls_bwd(self, ctx, srcs, H, W, layer, y, act, wo, cat2=None):
         q5, q4, q3, q2 = srcs
         dy = ctx.pop_grad(y)
         O, I, R, S, stride, pad = _geom(layer)
@@ -738,7 +789,10 @@ class Engine(object):
                 call("mpn_fill_f32", ops.ptr(dcomb), 0.0, n, ops.stream_ptr())
                 done = False
                 if wg:
-                    done = ops.conv_wgrad_cat([q3, q2], H, W, dy, dcomb[: wo.nm], O, db=ar.grad_seg(bias) if bg else None)
+                    if cat2 is None:
+                        done = ops.conv_wgrad_cat([q3, q2], H, W, dy, dcomb[: wo.nm], O, db=ar.grad_seg(bias) if bg else None)
+                    else:
+                        done = ops.conv_wgrad(cat2, dy, dcomb[: wo.nm], O, 3, 3, 1, 1, db=ar.grad_seg(bias) if bg else None)
                     ops.conv_wgrad(q5, g8, dcomb[wo.nm: wo.nm + wo.nt], 9 * O, 1, 1, 1, 0)
                     ops.conv_wgrad(q4, g4t, dcomb[wo.nm + wo.nt:], 9 * O, 1, 1, 1, 0)
                     call("mpn_conv2cls_fold", ops.ptr(dcomb), ops.ptr(ar.grad_seg(layer.weight)), O, C, ops.stream_ptr())
@@ -746,7 +800,7 @@ class Engine(object):
                     ops.bias_grad(dy, ar.grad_seg(bias), O)
                 ctx.side_keep.append((dcomb,))
             ctx.side_keep.append((p8, p4, g8, g4t))
-        self._on_side(ctx, dev, (srcs, dy, g5, g4, wo), class_side)
+        self._on_side(ctx, dev, (srcs, dy, g5, g4, wo, cat2), class_side)
         if self.side_stream(dev) is not None:
             self.flush_side(ctx, dev)
         if wg:
@@ -932,14 +986,15 @@ class Engine(object):
                 saved.append(self.export_internal(ctx, k, "k%d" % i) if internal else self.export(ctx, k, 19, Ho, Wo, "k%d" % i))
         q5, _ = self.conv(ctx, self.conv(ctx, p5, m.convt1)[0], m.convs1)
         q4, _ = self.conv(ctx, self.conv(ctx, p4, m.convt2)[0], m.convs2)
+        cls = self.conv2cls_begin(ctx, q5, q4, Ho, Wo, m.conv2) if (self.conv2_classes and (self.virtual_concat or not ops.is16(self.cdt))) else None
         if ctx.train:
             # backward: the gradients of q5 / q4 may come from the side stream (conv2 by position classes); this marker runs right
             # before the first launch that reads them (the tape is walked backwards)
             ctx.tape.append(lambda: self.wait_class_grads(ctx, p2.t.device))
         q3, _ = self.conv(ctx, self.conv(ctx, p3, m.convt3)[0], m.convs3)
         q2, _ = self.conv(ctx, self.conv(ctx, p2, m.convt4)[0], m.convs4)
-        if self.virtual_concat and self.conv2_classes and ops.conv2cls_supported([q5, q4, q3, q2], Ho, Wo):
-            h = self.conv_cat_cls(ctx, [q5, q4, q3, q2], Ho, Wo, m.conv2, act=1)
+        if cls is not None and ops.conv2cls_supported([q5, q4, q3, q2], Ho, Wo):
+            h = self.conv_cat_cls(ctx, [q5, q4, q3, q2], Ho, Wo, m.conv2, 1, cls)
         elif self.virtual_concat and ops.cat_supported([q5, q4, q3, q2], Ho, Wo):
             h = self.conv_cat(ctx, [q5, q4, q3, q2], Ho, Wo, m.conv2, act=1)
         else:

@@ -207,14 +207,14 @@ def set_lazy_log(on=True):
 
 
 class _Deferred(object):
-    """Placeholder for log value `i` of captured vector `slot` (a capturing stepper — tools/experiments_r2/hipgraph_step.py — turns it into a float / LazyFloat per replay)."""
+    """Placeholder for log value `i` of captured vector `slot` (a capturing stepper — tools/archive/r2/hipgraph_step.py — turns it into a float / LazyFloat per replay)."""
     __slots__ = ("slot", "i")
 
     def __init__(self, slot, i):
         self.slot, self.i = slot, i
 
 
-CAPTURE_LOG = None      # list of static device vectors while a hipGraph capture of a step is in progress (tools/experiments_r2/hipgraph_step.py) (no D2H copy inside a capture)
+CAPTURE_LOG = None      # list of static device vectors while a hipGraph capture of a step is in progress (tools/archive/r2/hipgraph_step.py) (no D2H copy inside a capture)
 
 
 def _log_values(t):

@@ -399,11 +399,13 @@ def conv_wgrad_cat(srcs, H, W, dy, dw, Cout, db=None):
 
 # ---- conv2 of the keypoint head by position classes (csrc/conv2cls.hip) -------------------------------------------------------------
 def conv2cls_supported(srcs, H, W):
-    """The class formulation serves exactly posenet.py:311-315's geometry: four 128-channel 16-bit members at 1/8, 1/4, 1/2, 1/1 of an
-    H x W (multiples of 8) output."""
-    if not cat_supported(srcs, H, W) or len(srcs) != 4 or H % 8 or W % 8:
+    """The class formulation serves exactly posenet.py:311-315's geometry: four dense 128-channel members of one element type at 1/8,
+    1/4, 1/2, 1/1 of an H x W (multiples of 8) output."""
+    if len(srcs) != 4 or H % 8 or W % 8:
         return False
-    return [(H // a.H, W // a.W) for a in srcs] == [(8, 8), (4, 4), (2, 2), (1, 1)]
+    if any(a.C != 128 or a.Cs != 128 or a.t.dtype != srcs[0].t.dtype or a.B != srcs[0].B for a in srcs):
+        return False
+    return [(a.H * f, a.W * f) for a, f in zip(srcs, (8, 4, 2, 1))] == [(H, W)] * 4
 
 
 class Conv2ClsOperands(object):
@@ -417,11 +419,15 @@ class Conv2ClsOperands(object):
         self.nm, self.nc, self.nt = O * 9 * 2 * C, 9 * O * 9 * C, 9 * O * C
         comb32 = torch.empty(n, dtype=torch.float32, device=dev)
         call("mpn_conv2cls_combine", ptr(w_master), ptr(comb32), O, C, stream_ptr())
-        nf = self.nm + 2 * self.nc                                              # forward operands: main filter + the two frame-filter sets
-        self.comb = torch.empty(nf, dtype=dtype, device=dev)
-        cast_lowp(comb32[:nf], self.comb)
+        nf = self.nm + 2 * self.nc                                              # main filter + the two frame-filter sets
+        if is16(dtype):
+            self.comb = torch.empty(n, dtype=dtype, device=dev)
+            cast_lowp(comb32, self.comb)
+        else:
+            self.comb = comb32                                                  # f32 kernels read the f32 filters in place
         self.wm = self.comb[: self.nm]                                         # [O][3][3][2C]
         self.wc = [self.comb[self.nm + m * self.nc: self.nm + (m + 1) * self.nc] for m in range(2)]      # [9 O][3][3][C], members q5 / q4
+        self.wtap = [self.comb[nf + m * self.nt: nf + (m + 1) * self.nt] for m in range(2)]              # [9 O][C]: nine 1x1 filters
         self.wm_t = self.wtap_t = None
         if want_t:
             self.wm_t = torch.empty((2 * C, 3, 3, O), dtype=dtype, device=dev)
@@ -447,6 +453,13 @@ def conv2cls_pool(dy):
     p4 = Act(torch.empty((B, H // 4, W // 4, 9 * O), dtype=dy.t.dtype, device=dy.t.device), 9 * O)
     call("mpn_conv2cls_pool", ptr(dy.t), ptr(p8.t), ptr(p4.t), B, H, W, O, dtype_code(dy.t.dtype), stream_ptr())
     return p8, p4
+
+
+def conv2cls_classsum(t):
+    """Per-tap products (f32 [B, h, w, 9 O]) -> class maps of the same shape (csrc/conv2cls.hip: conv2cls_classsum_kernel)."""
+    m = Act(torch.empty_like(t.t), t.C)
+    call("mpn_conv2cls_classsum", ptr(t.t), ptr(m.t), t.B, t.H, t.W, t.Cs // 9, stream_ptr())
+    return m
 
 
 def conv2cls_tapsum(pc):

@@ -6,7 +6,7 @@ per contiguous run of trainable parameters in the flat arena, instead of ~5 fore
 
 Every scalar of the update (lr, betas, eps, weight decay, bias corrections, step count) lives in a
 small DEVICE vector (include/mpn.h: mpn_adam_advance / mpn_adam_step_dev), so a training step captured
-in a hipGraph (tools/experiments_r2/hipgraph_step.py) replays correct Adam steps; the host only rewrites the vector when a
+in a hipGraph (tools/archive/r2/hipgraph_step.py) replays correct Adam steps; the host only rewrites the vector when a
 scheduler changes a hyper-parameter.
 
 ``state_dict()`` / ``load_state_dict()`` use torch.optim.Adam's own layout (per-parameter ``step``,

@@ -390,7 +390,7 @@ def test_wgrad_instantiations_match_torch(case, dtype):
     kernel (stride-1 same-extent convolutions over a dense x: tap offset in the buffer descriptor, k-step advance in the scalar offset,
     only the halo predicate per lane).  Shapes chosen for what that changes: borders in every k-step, k-steps spanning images, rows before
     and past the tensor, slices cut inside images, ragged tiles; and the shapes that must NOT take it.  (The same cases also passed on the
-    shared-tap 3x3 kernel of tools/experiments_r4/wgrad_shared_tap_s3.patch, which was measured and not kept.)"""
+    shared-tap 3x3 kernel of tools/archive/r4/wgrad_shared_tap_s3.patch, which was measured and not kept.)"""
     from multiposenet.pytorch_amd import ops
     (B, H, W, Cin, Cout, k, pad, stride), kind = case
     x = rnd(dtype, rng_normal(51, B, Cin, H, W))

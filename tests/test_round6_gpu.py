@@ -237,3 +237,90 @@ def test_conv2_by_position_classes_equals_the_virtual_concatenation(dtype):
     # the four members really take different routes: the class filters' gradient slices are non-zero and differ from each other
     dw = cls[1].reshape(256, 3, 3, 512)
     assert all(float(dw[..., k * 128:(k + 1) * 128].abs().max()) > 0 for k in range(4))
+
+
+def test_conv2_by_position_classes_in_fp32_is_the_same_arithmetic():
+    """fp32 (BASELINE config 2's arithmetic): the class formulation — forward per TAP (nine 1x1 convolutions of the low-resolution member
+    + class sums), expansion, the 3x3 convolution over the materialised (q3, q2) half, per-tap backward — against the plain fp32 path
+    (materialised 512-channel concatenation): identical mathematics, so the prediction agrees to fp32 summation order (<= 2e-5 rel-L2;
+    the 1e-3 abs heat-map gate of the goldens keeps three decades of headroom).  Gradients pass through conv2's ReLU: of its 2 M outputs
+    about two lie within 1e-6 of zero and take the other side of the kink in the other summation order; one flipped element is 1 / 64 of
+    its channel's bias gradient (a sum of ~4 000 random-sign terms), i.e. ~1.4e-3 rel-L2 over the 256 channels — measured 1.3e-3 / 1.4e-3
+    for dW / db at 64 x 64, which is that and nothing else (a wrong tap or class is 1e-1 or more): gate 5e-3.  Also a non-square 40 x 24 head."""
+    from test_model_gpu import get_model
+    from test_round4_gpu import _rel, _bf16_randn
+    m = get_model(50, torch.float32)
+    m.train()
+    saved = (m._engine.conv2_classes, m._engine.overlap_wgrad)
+    try:
+        for B, (Hh, Ww) in ((2, (64, 64)), (1, (40, 24))):
+            feats = [_bf16_randn(920 + i, B, 256, Hh >> i, Ww >> i, relu=True) for i in range(4)]
+            g_pred = _bf16_randn(930, B, 18, Hh, Ww, scale=0.05)
+            m._prepare(torch.zeros((B, 3, 4 * Hh, 4 * Ww), device="cuda"))
+            plain = _head_run(m, feats, g_pred, False, False)
+            cls = _head_run(m, feats, g_pred, True, True)
+            worst = max([_rel(cls[i], plain[i]) for i in range(1, 3)] + [_rel(cls[3][k], plain[3][k]) for k in cls[3]])
+            report("conv2 by position classes (fp32, %dx%d): prediction %.1e, conv2 dW %.1e, db %.1e, worst gradient %.1e vs the plain fp32 path"
+                   % (Hh, Ww, _rel(cls[0], plain[0]), _rel(cls[1], plain[1]), _rel(cls[2], plain[2]), worst))
+            assert _rel(cls[0], plain[0]) <= 2e-5 and worst <= 5e-3, (_rel(cls[0], plain[0]), worst)
+    finally:
+        m._engine.conv2_classes, m._engine.overlap_wgrad = saved
+
+
+# ------------------------------------------------------------------------------------------------ does it train, bf16 beside fp32
+def test_bf16_and_fp32_training_curves_fall_together():
+    """VERDICT r5 item 9 (tools/train_sanity.py as a gate): R50 full posenet, 128 x 128, 4 images, two fixed synthetic batches (Gaussian
+    heat-map targets rendered by datasets/heatmap.py, random person boxes), 32 recorded steps with FusedAdam at the reference's 1e-4
+    (training/multipose_keypoint_train.py:106-110), batch-statistics BatchNorm — once in bf16, once in fp32, same initial weights.
+    A SYSTEMATIC bf16 error (a dropped gradient term, a wrong rounding point, statistics from the wrong tensor) bends the bf16 curve away
+    from the fp32 one; rounding noise does not: the mean total loss of the last 8 steps must agree within 5 %, both curves must have
+    fallen, and the heat-map losses must agree within 5 % too.  (The full-size bf16 test accepts rel-L2 0.3 on the heat-maps of ONE
+    forward under batch statistics — test_round2_gpu.py:245 — which cannot see such a drift.)"""
+    from multiposenet.pytorch_amd.datasets.heatmap import put_gaussian_maps
+    from multiposenet.pytorch_amd.network.posenet import poseNet
+    from multiposenet.pytorch_amd.optim import FusedAdam
+    from multiposenet.pytorch_amd.replay import ReplayedTrainStep
+    from multiposenet.pytorch_amd import synthetic as weightgen
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(7)
+    S, B, steps = 128, 4, 32
+    batches = []
+    for _ in range(2):
+        img = torch.from_numpy(rs.uniform(-2, 2, (B, 3, S, S)).astype(np.float32)).to(dev)
+        joints = np.zeros((B, 2, 18, 3), np.float64)
+        joints[..., 0] = rs.uniform(8, S - 8, (B, 2, 18)); joints[..., 1] = rs.uniform(8, S - 8, (B, 2, 18)); joints[..., 2] = 1
+        heat = put_gaussian_maps(torch.from_numpy(joints).to(dev), torch.full((B,), 2, dtype=torch.int32, device=dev), S, S, stride=4, sigma=7.0)
+        anno = np.full((B, 8, 5), -1, np.float32)
+        for b in range(B):
+            for k in range(2):
+                x, y = rs.uniform(4, S - 70, 2); w, h = rs.uniform(30, 60, 2)
+                anno[b, k] = [x, y, x + w, y + h, 0]
+        batches.append((img, heat.contiguous(), torch.ones_like(heat), torch.from_numpy(anno).to(dev)))
+    curves = {}
+    for dt in (torch.bfloat16, torch.float32):
+        m = poseNet(50, compute_dtype=dt).to(dev)
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        sd = weightgen.gen_state_dict(shapes, seed=0, flavour="he", skip_prefixes=("prn.",))
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        for p in m.prn.parameters():
+            p.requires_grad = False
+        m.train()
+        step = ReplayedTrainStep(m, FusedAdam(m, lr=1e-4))
+        rows = []
+        for i in range(steps):
+            img, heat, wgt, anno = batches[i % 2]
+            loss, log = step([[img, "train_both"]], ["train_both", heat, wgt, anno])
+            rows.append((float(loss), float(log["heatmap_loss"])))
+        torch.cuda.synchronize()
+        assert step.replays >= steps - 4
+        curves[dt] = np.array(rows)
+        del step, m
+        torch.cuda.empty_cache()
+    b, f = curves[torch.bfloat16], curves[torch.float32]
+    assert np.isfinite(b).all() and np.isfinite(f).all()
+    tb, tf = b[-8:, 0].mean(), f[-8:, 0].mean()
+    hb, hf = b[-8:, 1].mean(), f[-8:, 1].mean()
+    report("does it train (R50 128x128 B=4, 32 recorded steps, lr 1e-4): total loss bf16 %.4f -> %.4f, fp32 %.4f -> %.4f (last-8 means %.1f %% apart); "
+           "heat-map loss %.5f / %.5f (%.1f %% apart)" % (b[0, 0], tb, f[0, 0], tf, 100 * abs(tb - tf) / tf, hb, hf, 100 * abs(hb - hf) / hf))
+    assert tb < 0.8 * b[:2, 0].mean() and tf < 0.8 * f[:2, 0].mean(), "the loss did not fall"
+    assert abs(tb - tf) <= 0.05 * tf and abs(hb - hf) <= 0.05 * hf
