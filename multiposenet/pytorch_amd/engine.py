@@ -105,10 +105,6 @@ class Engine(object):
         # ... and its x8 / x4 members do not go through conv2 at full resolution at all: nine position-class maps each at their own
         # resolution (csrc/conv2cls.hip), expanded into conv2's epilogue; conv2 itself contracts over the x2 / x1 members only
         self.conv2_classes = os.environ.get("MPN_CONV2_CLASSES", "1") != "0"
-        self.conv2_classes_own_stream = os.environ.get("MPN_CONV2_CLS_STREAM", "0") != "0"      # measured: 35.73 -> 35.91 ms (profiles/r06_conv2_classes_ab.txt)
-        self._cls_stream = None
-        # forward class maps per TAP (1x1 convolutions + class sums) instead of the 3x3 frame filters: always in f32, optional in 16 bits
-        self.conv2_fwd_taps = os.environ.get("MPN_CONV2_FWD_TAPS", "0") != "0"
 
     def side_stream(self, device):
         """Second HIP stream for weight/bias gradients.  They are off the backward critical path (only the
@@ -120,11 +116,6 @@ class Engine(object):
         if self._side is None:
             self._side = torch.cuda.Stream(device=device)
         return self._side
-
-    def class_stream(self, device):
-        if self._cls_stream is None:
-            self._cls_stream = torch.cuda.Stream(device=device)
-        return self._cls_stream
 
     def _on_side(self, ctx, device, keep, fn, torch_ops=False):
         """Run fn() on the side stream, ordered after everything enqueued so far on the current stream.  Our own
@@ -667,8 +658,7 @@ class Engine(object):
     def conv2cls_begin(self, ctx, q5, q4, H, W, layer):
         """First half of conv_cat_cls, issued as soon as the x8 / x4 members exist (before the x2 / x1 branches of the head are
         enqueued, so that it runs under them): combined filters, the two class convolutions, the expansion — on the weight-gradient
-        side stream, or on a stream of its own (MPN_CONV2_CLS_STREAM=1) when that one is busy with the detection pyramid.  Returns
-        the state conv_cat_cls consumes, or None when the geometry is not the class formulation's."""
+        side stream.  Returns the state conv_cat_cls consumes, or None when the geometry is not the class formulation's."""
         O, I, R, S, stride, pad = _geom(layer)
         if not (I == 512 and (R, S, stride, pad) == (3, 3, 1, 1) and H % 8 == 0 and W % 8 == 0 and q5.C == 128 and q4.C == 128
                 and q5.Cs == 128 and q4.Cs == 128 and (q5.H * 8, q5.W * 8, q4.H * 4, q4.W * 4) == (H, W, H, W) and q5.t.dtype == self.cdt):
@@ -681,9 +671,10 @@ class Engine(object):
         def classes():
             # (the transposed operands are made whenever a tape is being recorded: whether q3 / q2 need gradients is not known yet)
             st["ops"] = wo = ops.Conv2ClsOperands(ar.data_seg(layer.weight), O, C, self.cdt, ctx.train)
-            if self.conv2_fwd_taps or not ops.is16(self.cdt):
+            if not ops.is16(self.cdt):
                 # per TAP: nine 1x1 convolutions + a low-resolution class sum — 9x fewer FLOPs than the frame filters, which matters where
-                # the matrix pipe is the limit (f32); in 16 bits the extra f32 pass over the maps costs what the frames waste
+                # the matrix pipe is the limit (f32); in 16 bits the extra f32 pass over the maps costs more than the frames waste
+                # (headline step 36.57 -> 36.78 ms, profiles/r06_cfg2_conv2_classes_ab.txt)
                 t8, _ = ops.conv_forward(q5, wo.wtap[0], 9 * O, 1, 1, 1, 0, out_f32=True)
                 t4, _ = ops.conv_forward(q4, wo.wtap[1], 9 * O, 1, 1, 1, 0, out_f32=True)
                 m8, m4 = ops.conv2cls_classsum(t8), ops.conv2cls_classsum(t4)
@@ -693,18 +684,10 @@ class Engine(object):
                 m4, _ = ops.conv_forward(q4, wo.wc[1], 9 * O, 3, 3, 1, 1, out_f32=True)
                 st["keep"] = (m8, m4)
             st["e"] = ops.conv2cls_expand(m8, m4, q5.B, H, W, O, self.cdt)
+        # The weight-gradient side stream carries it (behind the detection pyramid, forked earlier): a stream of its own measured
+        # 0.2 ms SLOWER (profiles/r06_conv2_classes_ab.txt) — a third stream only adds contention.
         side = self.side_stream(dev)
-        if side is not None and self.conv2_classes_own_stream:
-            side = self.class_stream(dev)
-            ev0 = torch.cuda.Event()
-            gpu_op(ev0.record, torch.cuda.current_stream(dev))
-            gpu_op(side.wait_event, ev0)
-            ops.push_stream(side)
-            try:
-                classes()
-            finally:
-                ops.pop_stream()
-        elif side is not None:
+        if side is not None:
             self._on_side(ctx, dev, (q5, q4, st), classes)
             self.flush_side(ctx, dev)
         else:

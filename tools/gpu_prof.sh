@@ -11,7 +11,7 @@ cd $R
 for m in serial overlap; do
   DB=$(find $O/$m -name "*_results.db" | head -1)
   # bench: 2 set-up (1 eager + 1 recording) + 4 warm-up + 12 timed + 5 empty-queue host measurements = 23 steps
-  [ -n "$DB" ] && python tools/rocprof_summary.py "$DB" 23 "round 5, $m schedule, python bench.py --steps 12 --warmup 4 (23 steps incl. set-up and the 5 empty-queue host measurements), rocprofv3 --kernel-trace --stats" > $O/kernel_trace_$m.txt 2>&1
+  [ -n "$DB" ] && python tools/rocprof_summary.py "$DB" 23 "round ${MPN_ROUND:-6}, $m schedule, python bench.py --steps 12 --warmup 4 (23 steps incl. set-up and the 5 empty-queue host measurements), rocprofv3 --kernel-trace --stats" > $O/kernel_trace_$m.txt 2>&1
   [ -n "$DB" ] && rm -rf $O/$m
   grep '"metric"' $O/$m.out | cut -c1-300
 done
