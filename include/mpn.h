@@ -337,6 +337,9 @@ int mpn_bce_mean_forward(const float* p, const float* label, int64_t n, float* p
 /* img_w < 0 disables the clip (pure BBoxTransform) */
 int mpn_box_decode_clip(const float* anchors, const float* deltas, float* boxes, int B, int A,
                         float img_w, float img_h, void* stream);
+/* the same with BBoxTransform's optional coefficients (network/utils.py:8-17): mean_std = {mean[0..3], std[0..3]}, a HOST array */
+int mpn_box_decode_clip_ms(const float* anchors, const float* deltas, float* boxes, int B, int A, float img_w,
+                           float img_h, const float* mean_std, void* stream);
 int mpn_clip_boxes(float* boxes, int64_t n, float img_w, float img_h, void* stream);   /* in place, utils.py:55-59 */
 /* compact image-0 candidates with score > thresh into dets[n,5] (x1,y1,x2,y2,score) + src index;
  * order preserved (ascending anchor index).  count[0] receives n. */

@@ -139,6 +139,7 @@ SIGNATURES = {
     "mpn_bce_chunks": (_i, [_i64]),
     "mpn_bce_mean_forward": (_i, [_vp, _vp, _i64, _vp, _i, _vp, _vp]),
     "mpn_box_decode_clip": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _vp]),
+    "mpn_box_decode_clip_ms": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, ctypes.POINTER(ctypes.c_float), _vp]),
     "mpn_clip_boxes": (_i, [_vp, _i64, _f, _f, _vp]),
     "mpn_score_filter": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "mpn_score_filter_batched": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),

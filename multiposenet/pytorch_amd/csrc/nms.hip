@@ -25,16 +25,16 @@
 namespace {
 
 __global__ void box_decode_clip_kernel(const float* __restrict__ anchors, const float* __restrict__ deltas,
-                                       float* __restrict__ boxes, int B, int A, float img_w, float img_h) {
+                                       float* __restrict__ boxes, int B, int A, float img_w, float img_h, float4 mean, float4 std) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * A) return;
     const int a = (int)(i % A);
     const float4 an = *reinterpret_cast<const float4*>(anchors + (long)a * 4);
     const float4 d = *reinterpret_cast<const float4*>(deltas + i * 4);
-    // utils.py:21-41 (mean 0, std .1 .1 .2 .2)
+    // utils.py:21-41: deltas * std + mean (defaults mean 0, std .1 .1 .2 .2, utils.py:10-17)
     const float w = an.z - an.x, h = an.w - an.y;
     const float cx = an.x + 0.5f * w, cy = an.y + 0.5f * h;
-    const float dx = d.x * 0.1f, dy = d.y * 0.1f, dw = d.z * 0.2f, dh = d.w * 0.2f;
+    const float dx = d.x * std.x + mean.x, dy = d.y * std.y + mean.y, dw = d.z * std.z + mean.z, dh = d.w * std.w + mean.w;
     const float pcx = cx + dx * w, pcy = cy + dy * h;
     const float pw = expf(dw) * w, ph = expf(dh) * h;
     float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
@@ -266,7 +266,18 @@ extern "C" int mpn_box_decode_clip(const float* anchors, const float* deltas, fl
     MPN_CHECK_ARG(anchors && deltas && boxes && B > 0 && A > 0);
     const long n = (long)B * A;
     hipLaunchKernelGGL(box_decode_clip_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, anchors, deltas,
-                       boxes, B, A, img_w, img_h);
+                       boxes, B, A, img_w, img_h, make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.1f, 0.1f, 0.2f, 0.2f));
+    return mpn_launch_status();
+}
+
+// BBoxTransform(mean, std) with non-default coefficients (utils.py:8-17): mean_std = {mean[0..3], std[0..3]} on the HOST
+extern "C" int mpn_box_decode_clip_ms(const float* anchors, const float* deltas, float* boxes, int B, int A, float img_w,
+                                      float img_h, const float* mean_std, void* stream) {
+    MPN_CHECK_ARG(anchors && deltas && boxes && mean_std && B > 0 && A > 0);
+    const long n = (long)B * A;
+    hipLaunchKernelGGL(box_decode_clip_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, anchors, deltas,
+                       boxes, B, A, img_w, img_h, make_float4(mean_std[0], mean_std[1], mean_std[2], mean_std[3]),
+                       make_float4(mean_std[4], mean_std[5], mean_std[6], mean_std[7]));
     return mpn_launch_status();
 }
 

@@ -17,16 +17,23 @@ def decode_and_clip(anchors, deltas, img):
 
 
 class BBoxTransform(nn.Module):
-    """forward(boxes[1,A,4], deltas[B,A,4]) -> [B,A,4]; mean 0, std [.1,.1,.2,.2] (utils.py:8-16)."""
+    """forward(boxes[1,A,4], deltas[B,A,4]) -> [B,A,4]; deltas * std + mean with mean 0, std [.1,.1,.2,.2] unless given (utils.py:8-17)."""
 
     def __init__(self, mean=None, std=None):
         super(BBoxTransform, self).__init__()
+        # utils.py:10-17: optional 4-vectors (tensors / arrays); the defaults take the entry point with the constants compiled in
+        self.mean_std = None
         if mean is not None or std is not None:
-            raise NotImplementedError("only the reference defaults (mean 0, std .1/.1/.2/.2) are built")
+            m = [0.0] * 4 if mean is None else [float(v) for v in torch.as_tensor(mean).flatten().tolist()]
+            s_ = [0.1, 0.1, 0.2, 0.2] if std is None else [float(v) for v in torch.as_tensor(std).flatten().tolist()]
+            if len(m) != 4 or len(s_) != 4:
+                raise ValueError("BBoxTransform: mean and std are 4-vectors")
+            self.mean_std = m + s_
 
     def forward(self, boxes, deltas):
         # no clipping: pass an unbounded image size
-        return ops.box_decode_clip(boxes.reshape(-1, 4).contiguous(), deltas.detach().float().contiguous(), 0.0, 0.0, clip=False)
+        return ops.box_decode_clip(boxes.reshape(-1, 4).contiguous(), deltas.detach().float().contiguous(), 0.0, 0.0, clip=False,
+                                   mean_std=self.mean_std)
 
 
 class ClipBoxes(nn.Module):

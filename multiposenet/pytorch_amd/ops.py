@@ -952,11 +952,17 @@ def nms(dets, thresh, mode=0):
     return keep[:k]
 
 
-def box_decode_clip(anchors, deltas, img_w, img_h, clip=True):
+def box_decode_clip(anchors, deltas, img_w, img_h, clip=True, mean_std=None):
+    """mean_std: None = the reference defaults (mean 0, std .1 .1 .2 .2), or the eight floats (mean[0..3], std[0..3]) of
+    BBoxTransform(mean, std) (network/utils.py:8-17)."""
     B, A, _ = deltas.shape
     boxes = torch.empty((B, A, 4), dtype=torch.float32, device=deltas.device)
-    call("mpn_box_decode_clip", ptr(anchors), ptr(deltas), ptr(boxes), B, A, float(img_w) if clip else -1.0,
-         float(img_h) if clip else -1.0, stream_ptr())
+    w, h = (float(img_w), float(img_h)) if clip else (-1.0, -1.0)
+    if mean_std is None:
+        call("mpn_box_decode_clip", ptr(anchors), ptr(deltas), ptr(boxes), B, A, w, h, stream_ptr())
+    else:
+        ms = (ctypes.c_float * 8)(*[float(v) for v in mean_std])
+        call("mpn_box_decode_clip_ms", ptr(anchors), ptr(deltas), ptr(boxes), B, A, w, h, ms, stream_ptr())
     return boxes
 
 

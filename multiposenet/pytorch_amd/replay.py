@@ -164,7 +164,8 @@ class ReplayedTrainStep(object):
         m = self.model
         ar = m._arena
         return (id(ar), id(ar.grad_flat), tuple(p.requires_grad for p in ar.params), tuple(b.training for b in m._bns),
-                m.compute_dtype, id(m._reducer), m._engine.overlap_wgrad, m._engine.fork_every, id(self.opt._m), self.bucketed_update)
+                m.compute_dtype, id(m._reducer), m._engine.overlap_wgrad, m._engine.fork_every, id(self.opt._m), self.bucketed_update,
+                m._engine.conv2_classes, m._engine.virtual_concat)
 
     # ------------------------------------------------------------------ call
     def __call__(self, inputs, gts):

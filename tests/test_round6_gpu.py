@@ -326,3 +326,26 @@ def test_bf16_and_fp32_training_curves_fall_together():
            "heat-map loss %.5f / %.5f (%.1f %% apart)" % (b[0, 0], tb, f[0, 0], tf, 100 * abs(tb - tf) / tf, hb, hf, 100 * abs(hb - hf) / hf))
     assert tb < 0.8 * b[:2, 0].mean() and tf < 0.8 * f[:2, 0].mean(), "the loss did not fall"
     assert abs(hb - hf) <= 0.05 * hf and abs(tb - tf) <= 0.12 * tf
+
+
+def test_bbox_transform_with_given_mean_and_std():
+    """network/utils.py:8-48 with non-default coefficients (a reference option the hot path never takes; round 5 raised NotImplementedError):
+    deltas * std + mean -> centre / size decode, against the reference's formula evaluated in torch on the CPU; the default-coefficient
+    call is bit-identical to what it was (g6_decode.npz keeps gating that)."""
+    from multiposenet.pytorch_amd.network.utils import BBoxTransform
+    g = torch.Generator().manual_seed(5)
+    A, B = 777, 3
+    xy = torch.rand(A, 2, generator=g) * 300
+    boxes = torch.cat([xy, xy + 5 + torch.rand(A, 2, generator=g) * 120], 1)[None]
+    deltas = torch.randn(B, A, 4, generator=g)
+    mean, std = torch.tensor([0.05, -0.02, 0.1, 0.0]), torch.tensor([0.2, 0.15, 0.25, 0.3])
+    got = BBoxTransform(mean, std)(boxes.cuda(), deltas.cuda()).cpu()
+    w, h = boxes[:, :, 2] - boxes[:, :, 0], boxes[:, :, 3] - boxes[:, :, 1]
+    cx, cy = boxes[:, :, 0] + 0.5 * w, boxes[:, :, 1] + 0.5 * h
+    d = deltas * std + mean
+    pcx, pcy, pw, ph = cx + d[..., 0] * w, cy + d[..., 1] * h, torch.exp(d[..., 2]) * w, torch.exp(d[..., 3]) * h
+    ref = torch.stack([pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph], 2)
+    assert float((got - ref).abs().max()) <= 2e-3 and float(((got - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= 2e-6
+    dflt = BBoxTransform()(boxes.cuda(), deltas.cuda()).cpu()
+    expl = BBoxTransform([0, 0, 0, 0], [0.1, 0.1, 0.2, 0.2])(boxes.cuda(), deltas.cuda()).cpu()
+    assert torch.equal(dflt, expl)
