@@ -204,9 +204,12 @@ def pmc_traffic(kernel_class, tag=""):
         return None, None
     try:
         prof = json.load(open(files[-1]))
-        for k in prof["kernels"]:
-            if k["kernel"] == kernel_class:
-                return int(k["hbm_bytes_per_launch"]), "%s (library build %s)" % (os.path.basename(files[-1]), prof.get("build_id", "unrecorded"))
+        # the class name ops.py builds for the igemm kernels carries five template arguments, the trace's seven (..., EXT, PROF): exact
+        # match first, then the standard (non-extended) instantiation of the same five
+        hits = [k for k in prof["kernels"] if k["kernel"] == kernel_class] or \
+               [k for k in prof["kernels"] if k["kernel"] == kernel_class[:-1] + ", false, false>"]
+        if hits:
+            return int(hits[0]["hbm_bytes_per_launch"]), "%s (library build %s)" % (os.path.basename(files[-1]), prof.get("build_id", "unrecorded"))
         return None, None
     except Exception:
         return None, None

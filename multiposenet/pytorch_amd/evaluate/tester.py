@@ -216,62 +216,101 @@ class Tester(object):
         bboxs = self._boxes(scores, classification, transformed_anchors, scale)
         return self.prn_process(self._body_joints(joint_list), bboxs, file_name, image_id)
 
-    def infer_images_batched(self, images, file_names=None, image_ids=None, batch=64):
+    def infer_images_batched(self, images, file_names=None, image_ids=None, batch=64, pipeline=True):
         """``infer_image`` for many images with the network, the peak extraction and the PRN assignment running on whole batches:
         every image is padded to a square and resized to inp_size x inp_size (tester.py:203-213), so images of any size share a
         forward; per-image scales are applied to peaks and boxes afterwards.  Same result dicts, image by image, as
-        ``infer_image`` (tests/test_round3_gpu.py)."""
-        from ..network.joint_utils import NMS_batch_arrays, body_peaks_flat
-        from .prn_process import prn_assign_arrays
+        ``infer_image`` (tests/test_round3_gpu.py).
+
+        ``pipeline`` (round 6): the network of batch k + 1 is enqueued BEFORE batch k is post-processed, and the post-processing
+        launches (NMS, peaks, PRN forward, candidate compaction) go to a second stream that waits for batch k's network only — the
+        host's numpy work and its device reads run under the next batch's network instead of leaving the GPU idle (2 - 5 ms of a 33 ms
+        batch at 640 x 640 x 64).  Results are identical (same launches on the same data)."""
         n = len(images)
         file_names = file_names if file_names is not None else [''] * n
         image_ids = image_ids if image_ids is not None else [0] * n
         S = self.params.inp_size
         out = [None] * n
-        for i0 in range(0, n, batch):
-            idx = list(range(i0, min(n, i0 + batch)))
-            xs, scales = [], []
-            for i in idx:
-                img = _to_device_image(images[i], self.dev)
-                shape_dst = max(img.shape[0], img.shape[1])
-                scales.append(float(shape_dst) / S)
-                pad = abs(img.shape[1] - img.shape[0])
-                sq = torch.zeros((img.shape[0] + pad, img.shape[1] + pad, 3), dtype=torch.float32, device=self.dev)
-                sq[:img.shape[0], :img.shape[1]] = img
-                xs.append(resnet_preprocess(resize(sq[:shape_dst, :shape_dst], (S, S), cubic=False)))
-            with torch.no_grad():
-                heat, boxes, scores, kept = self.model.forward_all_images_padded(torch.stack(xs))
-            pk, cnt = NMS_batch_arrays({'thre1': 0.1}, heat, float(S) / heat.shape[2])
-            peaks_xy, joint_off = body_peaks_flat(pk, cnt)
-            sc = np.asarray(scales)
-            per_img = np.diff(np.concatenate([joint_off[:, 0], joint_off[-1:, 17]]))          # peaks per image
-            peaks_xy = peaks_xy * np.repeat(sc, per_img)[:, None]                             # get_joint_list: peaks * scale
-            nmax = boxes.shape[1]
-            if nmax:
-                # score > 0.5 among the kept rows (the single class is class 0 = person: forward_all_images_padded refuses anything else,
-                # so the reference's `classification == 0` filter, tester.py:232, holds by construction); masks built on the host from the
-                # two arrays that travel anyway
-                scores_h, boxes_h = scores.cpu().numpy(), boxes.cpu().numpy()
-                ok_h = (scores_h > 0.5) & (np.arange(nmax)[None, :] < np.asarray(kept)[:, None])
-            else:
-                ok_h, boxes_h = np.zeros((len(idx), 0), dtype=bool), np.zeros((len(idx), 0, 4), dtype=np.float32)
-            # boxes * scale in float32 like the reference's numpy expression (tester.py:228-234), image-major
-            b4 = (boxes_h[ok_h] * np.repeat(sc, ok_h.sum(1))[:, None].astype(np.float32)).astype(np.float64)
-            start = np.concatenate([[0], np.cumsum(ok_h.sum(1))]).astype(np.int32)
-            b4[:, 2:] -= b4[:, :2]
-            kp = prn_assign_arrays(self.model, peaks_xy, joint_off, b4, start, in_thres=self.params.in_thres)
-            for li, i in enumerate(idx):
-                res = []
-                for bi in range(start[li], start[li + 1]):
-                    k = np.zeros(51)
-                    k[0::3], k[1::3], k[2::3] = kp[bi, :, 0], kp[bi, :, 1], kp[bi, :, 2]
-                    pose_score = 0
-                    for f in range(17):
-                        pose_score += kp[bi, f, 2]
-                    res.append({'image_id': image_ids[i], 'file_name': file_names[i], 'category_id': 1, 'bbox': b4[bi].tolist(),
-                                'score': pose_score / 17.0, 'keypoints': k.tolist()})
-                out[i] = res
+        post = self._post_stream() if pipeline else None
+        pending = None
+        for i0 in list(range(0, n, batch)) + [None]:
+            nxt = None
+            if i0 is not None:
+                idx = list(range(i0, min(n, i0 + batch)))
+                xs, scales = [], []
+                for i in idx:
+                    img = _to_device_image(images[i], self.dev)
+                    shape_dst = max(img.shape[0], img.shape[1])
+                    scales.append(float(shape_dst) / S)
+                    pad = abs(img.shape[1] - img.shape[0])
+                    sq = torch.zeros((img.shape[0] + pad, img.shape[1] + pad, 3), dtype=torch.float32, device=self.dev)
+                    sq[:img.shape[0], :img.shape[1]] = img
+                    xs.append(resnet_preprocess(resize(sq[:shape_dst, :shape_dst], (S, S), cubic=False)))
+                with torch.no_grad():
+                    heat, anchors, cls, keep = self.model.forward_padded_begin(torch.stack(xs))
+                ev = None
+                if post is not None:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                nxt = (idx, scales, heat, anchors, cls, keep, ev)
+            if not pipeline and nxt is not None:
+                self._finish_batch(nxt, out, file_names, image_ids, None)
+                nxt = None
+            if pending is not None:
+                self._finish_batch(pending, out, file_names, image_ids, post)
+            pending = nxt
         return out
+
+    def _post_stream(self):
+        if getattr(self, '_post', None) is None:
+            self._post = torch.cuda.Stream(device=self.dev)
+        return self._post
+
+    def _finish_batch(self, item, out, file_names, image_ids, post):
+        """Detections, peaks and the PRN assignment of one batch whose network has been enqueued (infer_images_batched)."""
+        idx, scales, heat, anchors, cls, keep, ev = item
+        if post is not None:
+            post.wait_event(ev)
+            with torch.cuda.stream(post):
+                self._finish_batch_on_current_stream(idx, scales, heat, anchors, cls, out, file_names, image_ids)
+        else:
+            self._finish_batch_on_current_stream(idx, scales, heat, anchors, cls, out, file_names, image_ids)
+
+    def _finish_batch_on_current_stream(self, idx, scales, heat, anchors, cls, out, file_names, image_ids):
+        from ..network.joint_utils import NMS_batch_arrays, body_peaks_flat
+        from .prn_process import prn_assign_arrays
+        S = self.params.inp_size
+        boxes, scores, kept = self.model.detect_padded(anchors, cls)
+        pk, cnt = NMS_batch_arrays({'thre1': 0.1}, heat, float(S) / heat.shape[2])
+        peaks_xy, joint_off = body_peaks_flat(pk, cnt)
+        sc = np.asarray(scales)
+        per_img = np.diff(np.concatenate([joint_off[:, 0], joint_off[-1:, 17]]))          # peaks per image
+        peaks_xy = peaks_xy * np.repeat(sc, per_img)[:, None]                             # get_joint_list: peaks * scale
+        nmax = boxes.shape[1]
+        if nmax:
+            # score > 0.5 among the kept rows (the single class is class 0 = person: forward_all_images_padded refuses anything else,
+            # so the reference's `classification == 0` filter, tester.py:232, holds by construction); masks built on the host from the
+            # two arrays that travel anyway
+            scores_h, boxes_h = scores.cpu().numpy(), boxes.cpu().numpy()
+            ok_h = (scores_h > 0.5) & (np.arange(nmax)[None, :] < np.asarray(kept)[:, None])
+        else:
+            ok_h, boxes_h = np.zeros((len(idx), 0), dtype=bool), np.zeros((len(idx), 0, 4), dtype=np.float32)
+        # boxes * scale in float32 like the reference's numpy expression (tester.py:228-234), image-major
+        b4 = (boxes_h[ok_h] * np.repeat(sc, ok_h.sum(1))[:, None].astype(np.float32)).astype(np.float64)
+        start = np.concatenate([[0], np.cumsum(ok_h.sum(1))]).astype(np.int32)
+        b4[:, 2:] -= b4[:, :2]
+        kp = prn_assign_arrays(self.model, peaks_xy, joint_off, b4, start, in_thres=self.params.in_thres)
+        for li, i in enumerate(idx):
+            res = []
+            for bi in range(start[li], start[li + 1]):
+                k = np.zeros(51)
+                k[0::3], k[1::3], k[2::3] = kp[bi, :, 0], kp[bi, :, 1], kp[bi, :, 2]
+                pose_score = 0
+                for f in range(17):
+                    pose_score += kp[bi, f, 2]
+                res.append({'image_id': image_ids[i], 'file_name': file_names[i], 'category_id': 1, 'bbox': b4[bi].tolist(),
+                            'score': pose_score / 17.0, 'keypoints': k.tolist()})
+            out[i] = res
 
     def test(self, images):
         """tester.py:194-245 over decoded images: ``images`` maps file name -> [H, W, 3] BGR array.  With

@@ -329,6 +329,15 @@ class poseNet(nn.Module):
         """forward_all_images for batched post-processing: (heat-maps [B,18,H/4,W/4], boxes [B,nmax,4], scores [B,nmax], kept) with
         image b's detections in rows [:kept[b]] (descending score; single class) — no per-image tensors or Python lists.
         pre_nms_top_n: optional cap on the candidates that enter the suppression (ops.detect_batched; not in the reference)."""
+        predict_keypoint, transformed_anchors, classification, _keep = self.forward_padded_begin(img_batch)
+        boxes, scores, kept = self.detect_padded(transformed_anchors, classification, pre_nms_top_n)
+        return predict_keypoint, boxes, scores, kept
+
+    def forward_padded_begin(self, img_batch):
+        """First half of forward_all_images_padded: the network and the box decode are ENQUEUED, nothing is read back — the host returns
+        while the GPU still runs, so a serving loop can post-process the previous batch meanwhile (evaluate/tester.py:
+        infer_images_batched).  Returns (heat-maps, decoded boxes [B,A,4], scores [B,A,1], keep-alive): hold on to the last item until
+        this batch's results have been read (it owns tensors that side-stream launches of this forward still use)."""
         self._prepare(img_batch)
         eng = self._engine
         ctx = Ctx(False)
@@ -344,9 +353,13 @@ class poseNet(nn.Module):
             raise MpnError("forward_all_images_padded serves the single-class detector (classificationModel num_classes = 1), "
                                 "got %d classes" % classification.shape[-1])
         transformed_anchors = decode_and_clip(self.anchors(img_batch), regression, img_batch)
-        boxes, scores, kept = ops.detect_batched(transformed_anchors, classification.reshape(classification.shape[0], -1), 0.05, 0.5, padded=True,
-                                                 pre_nms_top_n=pre_nms_top_n)
-        return predict_keypoint, boxes, scores, kept
+        return predict_keypoint, transformed_anchors, classification, (ctx, regression)
+
+    @staticmethod
+    def detect_padded(transformed_anchors, classification, pre_nms_top_n=None):
+        """Second half: score filter + per-image NMS + gather on the CURRENT stream (two host reads)."""
+        return ops.detect_batched(transformed_anchors, classification.reshape(classification.shape[0], -1), 0.05, 0.5, padded=True,
+                                  pre_nms_top_n=pre_nms_top_n)
 
     def _entire_net(self, img_batch, all_images):
         self._prepare(img_batch)

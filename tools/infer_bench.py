@@ -76,12 +76,9 @@ def main():
     hv = h0.float().flatten()
     thre1 = float(torch.quantile(hv[torch.randperm(hv.numel(), device=hv.device)[:2000000]], 1.0 - args.people * 12.0 / (h0.shape[2] * h0.shape[3])))
 
-    def full_arrays():
-        """The chain on flat arrays: padded batch detections, peaks as one array, candidates compacted on the device, matching in
-        C++ (prn_assign_arrays); the 8 best NMS survivors of every image stand in for its people (no random-weight score exceeds
-        0.5).  Returns keypoints [boxes, 17, 3]."""
-        with torch.no_grad():
-            heat, boxes, scores, kept = m.forward_all_images_padded(img)
+    def finish_arrays(heat, anchors, cls):
+        """decode'd boxes -> NMS, peaks, PRN assignment on flat arrays, on the CURRENT stream."""
+        boxes, scores, kept = m.detect_padded(anchors, cls)
         pk, cnt = NMS_batch_arrays({'thre1': thre1}, heat, 4.0)
         peaks_xy, joint_off = body_peaks_flat(pk, cnt, keep=args.people)     # ... and at most `people` peaks per joint type reach the PRN stage
         nb = np.minimum(np.asarray(kept), args.people)
@@ -91,6 +88,37 @@ def main():
         ok = (b4[:, 2] >= 1) & (b4[:, 3] >= 1)
         start = np.concatenate([[0], np.cumsum(np.add.reduceat(ok, np.concatenate([[0], np.cumsum(nb)[:-1]])) if ok.size else nb * 0)]).astype(np.int32)
         return prn_assign_arrays(m, peaks_xy, joint_off, b4[ok], start)
+
+    def full_arrays():
+        """The chain on flat arrays: padded batch detections, peaks as one array, candidates compacted on the device, matching in
+        C++ (prn_assign_arrays); the 8 best NMS survivors of every image stand in for its people (no random-weight score exceeds
+        0.5).  Returns keypoints [boxes, 17, 3]."""
+        with torch.no_grad():
+            heat, anchors, cls, _keep = m.forward_padded_begin(img)
+        return finish_arrays(heat, anchors, cls)
+
+    post = torch.cuda.Stream()
+
+    def pipelined(nbatches):
+        """The same chain as a serving loop (Tester.infer_images_batched(pipeline=True)): batch k + 1's network is enqueued before batch k
+        is post-processed, and the post-processing launches go to a second stream that waits for batch k's network only."""
+        pending, last = None, None
+        for k in range(nbatches + 1):
+            nxt = None
+            if k < nbatches:
+                with torch.no_grad():
+                    item = m.forward_padded_begin(img)
+                ev = torch.cuda.Event()
+                ev.record()
+                nxt = (item, ev)
+            if pending is not None:
+                (heat, anchors, cls, _keep), ev = pending
+                post.wait_event(ev)
+                with torch.cuda.stream(post):
+                    last = finish_arrays(heat, anchors, cls)
+            pending = nxt
+        return last
+
     def full_lists():
         """The SAME workload as full_arrays() through the reference's list interface (tester.py:158-168: joint rows as a list of lists,
         boxes as a list per image -> prn_process_batch -> result dicts): what the interface itself costs."""
@@ -115,14 +143,27 @@ def main():
                      ("+ heat-map peaks + PRN assignment, reference list interface, threshold 0.1 (noise: hundreds of peaks per plane)", full),
                      ("+ heat-map peaks + PRN assignment (%d people / image; the SAME workload as the next line through the reference's list interface: "
                       "joint rows / boxes as Python lists in, result dicts out)" % args.people, full_lists),
-                     ("+ heat-map peaks + PRN assignment (%d people / image; flat arrays, compact candidates, C++ matching)" % args.people, full_arrays)):
-        fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.iters):
+                     ("+ heat-map peaks + PRN assignment (%d people / image; flat arrays, compact candidates, C++ matching)" % args.people, full_arrays),
+                     ("the same chain as a serving loop: next batch's network enqueued before this batch is post-processed, post-processing "
+                      "on a second stream (Tester.infer_images_batched(pipeline=True))", None)):
+        if fn is None:
+            ref = full_arrays()
+            got = pipelined(3)
+            assert np.array_equal(ref, got), "pipelined chain changed the results"
+            torch.cuda.synchronize()
+            nb = 3 * args.iters                                  # a serving loop runs for long: the one un-overlapped fill / drain step amortises
+            t0 = time.perf_counter()
+            pipelined(nb)
+            torch.cuda.synchronize()
+            dtm = (time.perf_counter() - t0) / nb
+        else:
             fn()
-        torch.cuda.synchronize()
-        dtm = (time.perf_counter() - t0) / args.iters
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.iters):
+                fn()
+            torch.cuda.synchronize()
+            dtm = (time.perf_counter() - t0) / args.iters
         print(json.dumps({"stage": name, "images_per_sec": round(args.batch / dtm, 1), "ms_per_batch": round(dtm * 1e3, 2), "batch": args.batch,
                           "size": args.size, "dtype": args.dtype, "bn_folded": not args.no_fold, "candidates_per_image": args.candidates}), flush=True)
 
