@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # one hardware queue per stream (main / wgrad side stream / RCCL), see the package __init__
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes); must be in place BEFORE the HSA runtime initialises
 
 import numpy as np
 import torch

@@ -88,6 +88,10 @@ def test_grad_reducer_schedule_for_r101_covers_every_trainable_element_once_in_r
         at_stem = bytes_at[ar.index[id(m.fpn.bn1.bias)]] / float(total)
         assert at_stem > 0.85 and at_layer1 > 0.85, (at_layer1, at_stem)
         assert len(red.buckets) >= 7
+        # round 6: the bucket that completes LAST (the first of the arena) is the tail no backward work hides: a quarter-size bucket
+        tail = red.buckets[launched[-1]]
+        assert launched[-1] == 0 and (tail["end"] - tail["start"]) * 4 <= 8.5 * 1024 * 1024 + 4 * max(ar.sizes[i] for i in tail["params"]), tail["end"] - tail["start"]
+        assert 1.0 - (tail["end"] - tail["start"]) / float(total) > 0.96
     finally:
         dist.destroy_process_group()
 
