@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/r6c20; mkdir -p $O
-for rep in 1 2; do for m in 0 1; do
+for rep in 1 2 3; do for m in 0 1; do
   MPN_CONV2_CLASSES=$m python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-kernel-events > $O/bench_cls${m}_$rep.json 2> $O/bench_cls${m}_$rep.err
   echo "conv2 classes=$m rep $rep: $(grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' $O/bench_cls${m}_$rep.json | tr '\n' ' ')"
 done; done
