@@ -129,4 +129,12 @@ def test_entry_points_reject_bad_arguments_without_touching_the_gpu():
     assert L.mpn_heatmap_peaks(one, 0, 0, 0, 0, 1, 18, 8, 8, 0.1, 4.0, 1, one, one, 0, one, nul) == BAD       # cap == 0
     assert L.mpn_heatmap_peaks(one, 0, 0, 0, 0, 1, 18, 8, 8, 0.1, 4.0, 1, one, one, 16, nul, nul) == BAD     # no workspace
     assert L.mpn_heatmap_peaks_workspace_bytes(64, 18, 160, 160, 256) == (64 * 18 * 160 * 3 * 8 + 255) // 256 * 256 + 64 * 18 * 256 * 4 + 256
+    # round 6 entry points: conv2 by position classes (H, W multiples of 8; channel counts multiples of 8; known dtype), BBoxTransform coefficients
+    assert L.mpn_conv2cls_comb_elems(256, 128) == 256 * 9 * 256 + 2 * 9 * 256 * 9 * 128 + 2 * 9 * 256 * 128 and L.mpn_conv2cls_comb_elems(0, 128) == 0
+    assert L.mpn_conv2cls_combine(nul, one, 256, 128, nul) == BAD and L.mpn_conv2cls_fold(one, nul, 256, 128, nul) == BAD
+    assert L.mpn_conv2cls_expand(one, one, one, 1, 12, 16, 256, 1, nul) == BAD        # H not a multiple of 8
+    assert L.mpn_conv2cls_expand(one, one, one, 1, 16, 16, 256, 7, nul) == BAD        # unknown dtype
+    assert L.mpn_conv2cls_pool(one, one, one, 1, 16, 16, 250, 1, nul) == BAD          # channels not a multiple of 8
+    assert L.mpn_conv2cls_tapsum(one, nul, 1, 2, 2, 256, 1, nul) == BAD and L.mpn_conv2cls_classsum(nul, one, 1, 2, 2, 256, nul) == BAD
+    assert L.mpn_box_decode_clip_ms(one, one, one, 1, 4, 10.0, 10.0, None, nul) == BAD
     assert L.mpn_nms(nul, 4, 0.5, 0, one, one, one, nul) != 0
