@@ -445,6 +445,10 @@ def main():
                                   "replay": "recorded launch list re-issued per step (replay.py)"}[args.launch]
                                  + ("" if gstep is None else ", %d replays" % gstep.replays)},
         }
+        out["config"]["optimizer_update"] = ("Adam bucket by bucket behind each all-reduce (finishing stream)" if (gstep is not None and gstep.bucketed_update)
+                                             else "Adam in one launch after backward")
+        out["config"]["conv2"] = ("keypoint head's conv2 by position classes (x8 / x4 members at their own resolution)" if model._engine.conv2_classes
+                                  else "conv2 over the virtual 512-channel concatenation")
         if dist_info is not None:
             out["dist"] = dist_info
         if args.shared_device_test:
