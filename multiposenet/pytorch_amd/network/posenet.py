@@ -378,12 +378,15 @@ class poseNet(nn.Module):
             # every image thresholded (posenet.py:269-271), NMS'd (:281) and gathered (:283-285) by batch-wide launches;
             # sizes stay on the device between the stages (ops.detect_batched: two host reads per BATCH)
             cls2 = classification.reshape(classification.shape[0], -1)
-            for boxes, nms_scores in ops.detect_batched(transformed_anchors, cls2, 0.05, 0.5):
+            dets = ops.detect_batched(transformed_anchors, cls2, 0.05, 0.5)
+            # single class: the arg-max class of every detection (posenet.py:283) is 0 — ONE zero vector for the batch, a view per image
+            most = max([b.shape[0] for b, _ in dets if b is not None], default=0)
+            zeros = torch.zeros(most, dtype=torch.int64, device=img_batch.device) if most else None
+            for boxes, nms_scores in dets:
                 if boxes is None:
                     results.append([torch.zeros(0), torch.zeros(0), torch.zeros(0, 4)])      # posenet.py:273-275 (CPU empties)
                 else:
-                    nms_class = torch.zeros(nms_scores.shape[0], dtype=torch.int64, device=nms_scores.device)   # single class
-                    results.append([nms_scores, nms_class, boxes])
+                    results.append([nms_scores, zeros[: nms_scores.shape[0]], boxes])
             return predict_keypoint, results
         for b in range(1):
             # posenet.py:269-275: score > 0.05, early-out with the CPU empty triple
